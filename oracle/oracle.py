@@ -1,0 +1,433 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+numpy + plain-C (oracle/tip_oracle.c) restatement of the reference's hot path
+(SURVEY.md section 8a).  Every function cites the reference lines it follows.  It
+is pinned by tests/golden/*.npz, which were produced by running the reference
+itself under the build container's Anaconda interpreter
+(tools/make_goldens.py).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product package never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libtip_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libtip_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_gaussian_weights.restype = ctypes.c_long
+        _LIB.orc_label4_i32.restype = ctypes.c_long
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+_MODES = {"nearest": 0, "reflect": 1, "constant": 2, "mirror": 3, "wrap": 4}
+
+
+# ----------------------------------------------------------------------------- Gaussian (bim.py:373-390)
+TAP_OVERRIDE = {}  # {sigma: taps}; tests inject the golden environment's taps here (np.exp differs by build)
+
+
+def gaussian_kernel1d(sigma, truncate=4.0):
+    """scipy/ndimage/filters.py:_gaussian_kernel1d (order 0) exactly as scipy's Python layer builds it.
+    np.exp is not correctly rounded and differs between numpy builds in the last bit, so the taps belong to
+    the environment; TAP_OVERRIDE lets the golden tests use the taps of the interpreter that made the goldens."""
+    sd = float(sigma)
+    if truncate == 4.0 and sd in TAP_OVERRIDE:
+        return np.asarray(TAP_OVERRIDE[sd], dtype=np.float64)
+    radius = int(truncate * sd + 0.5)
+    sigma2 = sd * sd
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    phi_x = phi_x / phi_x.sum()
+    return phi_x
+
+
+def correlate1d(a, weights, axis, mode="nearest", cval=0.0):
+    a = np.ascontiguousarray(a)
+    assert a.dtype in (np.float32, np.float64)
+    out = np.empty_like(a)
+    shape3 = (1,) * (3 - a.ndim) + a.shape
+    dims = (ctypes.c_long * 3)(*shape3)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    rc = lib().orc_correlate1d(_p(a), _p(out), 0 if a.dtype == np.float32 else 1, dims,
+                               axis + (3 - a.ndim), _p(w), ctypes.c_long(w.size), _MODES[mode],
+                               ctypes.c_double(cval))
+    assert rc == 0
+    return out
+
+
+def gaussian_filter(a, sigma, mode="nearest", truncate=4.0):
+    """scipy.ndimage.gaussian_filter as called by blur_image (bim.py:389): one correlate1d per axis in axis
+    order, axes with sigma <= 1e-15 skipped, output dtype == input dtype (rounded after every axis)."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        raise TypeError("oracle gaussian_filter handles float32/float64 only")
+    sig = np.ravel(np.asarray(sigma, dtype=np.float64))
+    if sig.size == 1:
+        sig = np.repeat(sig, a.ndim)
+    if sig.size != a.ndim:
+        raise RuntimeError("sequence argument must have length equal to input rank")
+    out = a
+    done = False
+    for ax in range(a.ndim):
+        if sig[ax] > 1e-15:
+            out = correlate1d(out, gaussian_kernel1d(sig[ax], truncate)[::-1], ax, mode)
+            done = True
+    return out if done else a.copy()
+
+
+def blur_image(image, std):
+    """bim.py:373-390."""
+    return gaussian_filter(image, std, mode="nearest")
+
+
+# ----------------------------------------------------------------------------- percentile (sp.py:33-36)
+def percentile_linear(a, q):
+    """np.percentile(a, q) for a 1-D float array with numpy 1.26.4 arithmetic (the oracle interpreter):
+    virtual index n*q' + (1 - q') - 1 with q' = q/100, previous/next order statistics, and
+    _lerp: a + (b-a)*t, replaced by b - (b-a)*(1-t) when t >= 0.5; (b-a) is formed in the array dtype,
+    the rest in float64.  Returns a float64 scalar."""
+    a = np.sort(np.ravel(a))
+    n = a.size
+    quant = np.true_divide(q, 100)
+    virtual = n * quant + (1 + quant * (1 - 1 - 1)) - 1
+    prev = int(np.floor(virtual))
+    gamma = np.float64(virtual - prev)
+    prev = min(max(prev, 0), n - 1)
+    nxt = min(prev + 1, n - 1)
+    lo, hi = a[prev], a[nxt]
+    diff = np.float64(hi - lo)  # subtraction in the array dtype, then widened
+    res = np.float64(lo) + diff * gamma
+    if gamma >= 0.5:
+        res = np.float64(hi) - diff * (1 - gamma)
+    return np.float64(res)
+
+
+# ----------------------------------------------------------------------------- projection (sp.py:17-85)
+def put_channel_axis_first(image, axes):
+    """bim.py:199-231 (note: only transposes when the C axis index is > 0; order is C,(T),(Z),X,Y)."""
+    c = axes.find("C")
+    if c > 0:
+        t, x, y, z = axes.find("T"), axes.find("X"), axes.find("Y"), axes.find("Z")
+        order = (x, y)
+        if z >= 0:
+            order = (z,) + order
+        if t >= 0:
+            order = (t,) + order
+        order = (c,) + order
+        return np.transpose(image, axes=order), order
+    return image, tuple(np.arange(len(axes)))
+
+
+def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, max_z=0,
+                                  method="max_averages", bin_size=1, airyscan=True, z_map=False,
+                                  atoh_shift=0, build_manifold=False):
+    """sp.py:17-85, bin_size == 1 / build_manifold False path (the only one BASELINE configs use)."""
+    if bin_size != 1 or build_manifold:
+        raise NotImplementedError("oracle covers bin_size=1, build_manifold=False")
+    if axes.find("T") >= 0:
+        time_point = time_point.reshape(time_point.shape[1:])
+        image, _ = put_channel_axis_first(time_point, axes[1:])
+    else:
+        image, _ = put_channel_axis_first(time_point, axes)
+    image = image.astype("float32")
+    if airyscan:
+        image -= 10000
+        image[image < 0] = 0
+    if max_z > 0:
+        image = image[:, min_z:max_z, :, :]
+    ch = np.copy(image[reference_channel])
+    nz = ch[ch > 0]
+    if nz.size > 0:
+        p95 = percentile_linear(nz, 95)
+        # numpy 1.x value-based casting: the float64 scalar is compared/assigned as float32
+        p95_32 = np.float32(p95)
+        ch[ch > p95_32] = p95_32
+    ch = blur_image(ch, (0.5, 1, 1))
+    z_size, y_size, x_size = image.shape[-3:]
+    score = blur_image(ch, (0.5, 30, 30))
+    chosen_z = min_z + np.argmax(score, axis=0)
+    chosen_z_atoh = np.copy(chosen_z) if atoh_shift == 0 else np.clip(chosen_z + atoh_shift, 0, score.shape[0])
+    mask = np.zeros((z_size, y_size * x_size), np.float32)
+    mask_atoh = np.zeros((z_size, y_size * x_size), np.float32)
+    mask[chosen_z.ravel(), np.arange(x_size * y_size)] = 1
+    mask_atoh[chosen_z_atoh.ravel(), np.arange(x_size * y_size)] = 1
+    mask = blur_image(mask.reshape((z_size, y_size, x_size)), (1, 2, 2))
+    mask_atoh = blur_image(mask_atoh.reshape((z_size, y_size, x_size)), (1, 2, 2))
+    if axes.find("C") >= 0:
+        channels = image.shape[0]
+        projection = np.zeros((channels, y_size, x_size))
+        for c in range(channels):
+            m = mask if c == reference_channel else mask_atoh
+            projection[c] = np.max(image[c] * m, axis=0)
+    else:
+        projection = np.max(image * mask, axis=0)
+    return (projection, chosen_z) if z_map else projection
+
+
+# ----------------------------------------------------------------------------- rank filters
+def _minmax(a, size=None, footprint=None, mode="reflect", is_max=True):
+    a = np.ascontiguousarray(a)
+    if footprint is not None:
+        fp = np.ascontiguousarray(np.asarray(footprint) != 0, dtype=np.uint8)
+        ky, kx = fp.shape
+        fpp = _p(fp)
+    else:
+        ky, kx = (size, size) if np.isscalar(size) else size
+        fp, fpp = None, None
+    if a.dtype == np.float64:
+        fn = lib().orc_minmax2d_f64
+    elif a.dtype == np.int32:
+        fn = lib().orc_minmax2d_i32
+    else:
+        raise TypeError(a.dtype)
+    out = np.empty_like(a)
+    rc = fn(_p(a), _p(out), ctypes.c_long(a.shape[0]), ctypes.c_long(a.shape[1]), ctypes.c_long(ky),
+            ctypes.c_long(kx), fpp, _MODES[mode], 1 if is_max else 0)
+    assert rc == 0
+    return out
+
+
+def maximum_filter(a, size=None, footprint=None, mode="reflect"):
+    """scipy.ndimage.maximum_filter (ti.py:1822 5x5 constant; ti.py:2081,2969 3x3 constant; ti.py:4079 cross)."""
+    return _minmax(a, size, footprint, mode, True)
+
+
+def minimum_filter(a, size=None, footprint=None, mode="reflect"):
+    """scipy.ndimage.minimum_filter (ti.py:4083 cross footprint, constant)."""
+    return _minmax(a, size, footprint, mode, False)
+
+
+def dilation(a, k):
+    """skimage.morphology.dilation with a k x k ones footprint (pl.py:170,173,193) = max filter, reflect."""
+    return _minmax(np.asarray(a, np.float64), k, None, "reflect", True)
+
+
+def erosion(a, k):
+    """skimage.morphology.erosion with a k x k ones footprint (pl.py:171,174,191) = min filter, reflect."""
+    return _minmax(np.asarray(a, np.float64), k, None, "reflect", False)
+
+
+def threshold_local_generic_max(image, imgthresh, blocksize):
+    """bim.py:464-472: threshold_local(method='generic', param=imgthresh*max) == imgthresh * max filter
+    (block x block, reflect) evaluated in float64 (skimage/filters/thresholding.py:210-213)."""
+    if blocksize % 2 == 0:
+        blocksize += 1
+    return imgthresh * _minmax(np.asarray(image, np.float64), blocksize, None, "reflect", True)
+
+
+# ----------------------------------------------------------------------------- labelling / watershed
+def label4(a, background=0):
+    """skimage.measure.label(a, connectivity=1, background=bg) (ti.py:2922,3470)."""
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    out = np.empty_like(a)
+    n = lib().orc_label4_i32(_p(a), ctypes.c_int32(background), _p(out), ctypes.c_long(a.shape[0]),
+                             ctypes.c_long(a.shape[1]))
+    return out, int(n)
+
+
+def local_minima(img):
+    """skimage.morphology.local_minima(img, connectivity=1) (called by watershed, _watershed.py:75)."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.empty(img.shape, np.uint8)
+    rc = lib().orc_local_minima_f64(_p(img), _p(out), ctypes.c_long(img.shape[0]), ctypes.c_long(img.shape[1]))
+    assert rc == 0
+    return out
+
+
+def watershed(img, markers=None, watershed_line=True):
+    """skimage.segmentation.watershed(img, markers=None, connectivity=1, watershed_line=...) (bim.py:475, pl.py:194)."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    if markers is None:
+        markers, _ = label4(local_minima(img).astype(np.int32), 0)
+    lab = np.ascontiguousarray(markers, dtype=np.int32).copy()
+    rc = lib().orc_watershed_f64(_p(img), _p(lab), ctypes.c_long(img.shape[0]), ctypes.c_long(img.shape[1]),
+                                 1 if watershed_line else 0)
+    assert rc == 0
+    return lab
+
+
+def watershed_segmentation(image, imgthresh, stdeviation, blocksize):
+    """bim.py:446-476 (the 4-argument definition that shadows bim.py:417-443)."""
+    seg = np.copy(image)
+    thr = threshold_local_generic_max(seg, imgthresh, blocksize)
+    seg[seg < thr] = 0
+    blurred = blur_image(seg, stdeviation)
+    return watershed(blurred, watershed_line=True)
+
+
+# ----------------------------------------------------------------------------- cell tables (ti.py:880-909, 1815-1842)
+_SQ2 = np.sqrt(2.0)
+
+
+def regionprops(labels, intensity=None):
+    """skimage.measure.regionprops_table(labels, properties=[label, area, perimeter, centroid, bbox]) (ti.py:891)
+    as a dict of arrays over labels 1..max (absent labels have area 0)."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    n = int(labels.max()) if labels.size else 0
+    area = np.zeros(n, np.int64)
+    bbox = np.zeros((n, 4), np.int64)
+    sy = np.zeros(n, np.int64)
+    sx = np.zeros(n, np.int64)
+    pc = np.zeros((n, 3), np.int64)
+    isum = np.zeros(n, np.float64) if intensity is not None else None
+    inten = np.ascontiguousarray(intensity, dtype=np.float64) if intensity is not None else None
+    rc = lib().orc_regionprops_i32(_p(labels), _p(inten) if inten is not None else None,
+                                   ctypes.c_long(labels.shape[0]), ctypes.c_long(labels.shape[1]), ctypes.c_long(n),
+                                   _p(area), _p(bbox), _p(sy), _p(sx), _p(pc), _p(isum) if isum is not None else None)
+    assert rc == 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cy = sy / area
+        cx = sx / area
+    perim = pc[:, 0] * 1.0 + pc[:, 1] * _SQ2 + pc[:, 2] * ((1 + _SQ2) / 2)
+    res = dict(label=np.arange(1, n + 1), area=area, bbox=bbox, cy=cy, cx=cx, perimeter=perim)
+    if isum is not None:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            res["intensity_mean"] = isum / area
+    return res
+
+
+def neighbor_pairs(labels):
+    """Unique (hi, lo) label pairs such that a pixel labelled lo>0 has hi as the max of its 5x5 window
+    (zero padded) -- the relation find_neighbors evaluates with labels[dilated == i] (ti.py:1822-1835)."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    dil = maximum_filter(labels, (5, 5), mode="constant")
+    sel = (labels > 0) & (dil != labels)
+    pairs = np.unique(np.stack([dil[sel], labels[sel]], axis=1), axis=0)
+    return pairs.astype(np.int64)
+
+
+def frame_cellinfo(labels, min_cell_area=0.1, max_cell_area=10):
+    """Tissue.calculate_frame_cellinfo + find_neighbors (ti.py:880-909, 1815-1842) as plain arrays.
+    Returns dict with area, perimeter, label, cx, cy, bbox columns, valid, neighbors (list of sets), n_neighbors."""
+    n = int(np.max(labels))
+    rp = regionprops(labels)
+    present = rp["area"] > 0
+    area = np.where(present, rp["area"], 0)
+    mean_area = np.mean(area)
+    valid = np.logical_and(area < max_cell_area * mean_area, area > min_cell_area * mean_area).astype(int)
+    pairs = neighbor_pairs(labels)
+    neighbors = [set() for _ in range(n)]
+    working = set((np.nonzero(valid)[0] + 1).tolist())
+    for hi, lo in pairs:
+        if int(hi) in working:
+            neighbors[hi - 1].add(int(lo))
+            neighbors[lo - 1].add(int(hi))
+    n_nb = np.array([len(s) for s in neighbors])
+    return dict(label=np.where(present, rp["label"], 0), area=area,
+                perimeter=np.where(present, rp["perimeter"], 0.0),
+                cx=np.where(present, rp["cx"], 0.0), cy=np.where(present, rp["cy"], 0.0),
+                bbox=np.where(present[:, None], rp["bbox"], 0), valid=valid, neighbors=neighbors, n_neighbors=n_nb)
+
+
+def update_labels(labels):
+    """Tissue.update_labels (ti.py:2967-2970): negative pixels take the 3x3 zero-padded maximum."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32).copy()
+    dil = maximum_filter(labels, (3, 3), mode="constant")
+    labels[labels < 0] = dil[labels < 0]
+    return labels
+
+
+def contact_matrix(labels, neighbors):
+    """calc_neighbors_contact_matrix / calculate_contact_length (ti.py:1844-1872, 4073-4094): for each cell and
+    each of its neighbours, the number of pixels whose cross-footprint max is the larger label and whose
+    cross-footprint min (zeros replaced by max+1) is the smaller one, inside bbox +-2."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    cross = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    mx = maximum_filter(labels, footprint=cross, mode="constant")
+    lc = labels.copy()
+    lc[lc == 0] = labels.max() + 1
+    mn = minimum_filter(lc, footprint=cross, mode="constant")
+    n = len(neighbors)
+    rp = regionprops(labels)
+    out = np.zeros((n, n))
+    for i in range(n):
+        if rp["area"][i] == 0:
+            r0 = c0 = 0
+            r1 = c1 = 2
+        else:
+            b = rp["bbox"][i]
+            r0, c0, r1, c1 = max(0, b[0] - 2), max(0, b[1] - 2), b[2] + 2, b[3] + 2
+        mxr, mnr = mx[r0:r1, c0:c1], mn[r0:r1, c0:c1]
+        for nb in neighbors[i]:
+            hi, lo = max(i + 1, nb), min(i + 1, nb)
+            out[i, nb - 1] = np.sum(np.logical_and(mxr == hi, mnr == lo))
+    return out
+
+
+def track_simple(labels_list, tables, drifts):
+    """Tissue.track_cells_iterator with existing drifts (ti.py:2037-2113): previous centroids minus drift are
+    looked up in the 3x3-max-filtered label map of the current frame; ids propagate, duplicates are resolved by
+    np.unique first-occurrence, unmatched cells get fresh ids.  Returns the per-frame id arrays."""
+    ids0 = tables[0]["label"].astype(np.int64).copy()
+    unl = ids0 == 0
+    last = ids0.max()
+    ids0[unl] = np.arange(last + 1, last + unl.sum() + 1)
+    out = [ids0]
+    cx_prev = tables[0]["cx"].astype(np.float64).copy()
+    cy_prev = tables[0]["cy"].astype(np.float64).copy()
+    ids_prev = ids0
+    for f in range(1, len(labels_list)):
+        cx_prev = cx_prev - drifts[f][1]
+        cy_prev = cy_prev - drifts[f][0]
+        lab = maximum_filter(np.ascontiguousarray(labels_list[f], np.int32), (3, 3), mode="constant")
+        n_cur = tables[f]["cx"].size
+        ids = np.zeros(n_cur, np.int64)
+        idx = -1 * np.ones(cy_prev.shape)
+        yl = np.round(cy_prev).astype(int)
+        xl = np.round(cx_prev).astype(int)
+        ok = (0 <= yl) & (yl < lab.shape[0]) & (0 <= xl) & (xl < lab.shape[1])
+        idx[ok] = lab[yl[ok], xl[ok]] - 1
+        lp = ids_prev[idx >= 0]
+        idx = idx[idx >= 0]
+        _, loc = np.unique(lp, return_index=True)
+        idx, lp = idx[loc], lp[loc]
+        _, loc = np.unique(idx, return_index=True)
+        idx, lp = idx[loc], lp[loc]
+        ids[idx.astype(int)] = lp
+        unl = ids == 0
+        last = ids.max()
+        ids[unl] = np.arange(last + 1, last + unl.sum() + 1)
+        out.append(ids)
+        cx_prev = tables[f]["cx"].astype(np.float64).copy()
+        cy_prev = tables[f]["cy"].astype(np.float64).copy()
+        ids_prev = ids
+    return out
+
+
+def tracking_labels(labels, ids):
+    """Tissue.get_trackking_labels (ti.py:4021-4028): per-pixel label -> track id LUT gather."""
+    lut = np.insert(np.asarray(ids), 0, 0)
+    return lut[labels]
+
+
+def closing_tail(p0, thr=0.1):
+    """prediction_local.py:167-194 after the network: threshold, 5x5 closing x101, 7x7 erosion, boundary, watershed."""
+    hcb = np.zeros(p0.shape)
+    hcb[p0 > thr] = 255
+    d = dilation(hcb, 5)
+    e = erosion(d, 5)
+    for _ in range(100):
+        d = dilation(e, 5)
+        e = erosion(d, 5)
+    hc = erosion(e, 7)
+    bound = e - hc
+    boundary = dilation(bound, 5)
+    return watershed(boundary, watershed_line=True), hc, boundary, e

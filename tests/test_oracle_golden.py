@@ -1,0 +1,198 @@
+"""Pins the CPU oracle (oracle/) against golden vectors generated from the reference itself
+(tools/make_goldens.py under the container's Anaconda interpreter).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+@pytest.fixture(autouse=True)
+def _taps(oracle_with_golden_taps):
+    # goldens were produced with numpy 1.26.4's (not correctly rounded) np.exp; use that environment's taps
+    yield
+
+
+def test_gaussian_bit_exact(golden):
+    g = golden("gaussian")
+    vol = g["vol_f32"]
+    for tag, sig in [("s05_1_1", (0.5, 1, 1)), ("s05_30_30", (0.5, 30, 30)), ("s1_2_2", (1, 2, 2))]:
+        out = orc.blur_image(vol, sig)
+        assert out.dtype == np.float32
+        np.testing.assert_array_equal(out, g["out_" + tag], err_msg=tag)
+    np.testing.assert_array_equal(orc.blur_image(g["img_f64"], 3), g["out2d_s3"])
+    np.testing.assert_array_equal(orc.blur_image(g["img_f64"], 7), g["out2d_s7"])
+    np.testing.assert_array_equal(orc.blur_image(g["img_f64"].astype(np.float32), 3), g["out2d_f32_s3"])
+    np.testing.assert_array_equal(orc.blur_image(g["tiny_f32"], (0.5, 30, 30)), g["tiny_out_s05_30_30"])
+
+
+def test_gaussian_weights_c_matches_numpy():
+    # libm exp (correctly rounded) vs np.exp (last-bit differences by numpy build): agree to ~2 ulp
+    import ctypes
+    for sigma in (0.5, 1.0, 2.0, 3.0, 7.0, 30.0):
+        w = np.zeros(512)
+        n = orc.lib().orc_gaussian_weights(ctypes.c_double(sigma), ctypes.c_double(4.0), orc._p(w), ctypes.c_long(512))
+        ref = orc.gaussian_kernel1d(sigma)
+        assert n == ref.size
+        np.testing.assert_allclose(w[:n], ref, rtol=2e-15, atol=0)
+
+
+def test_percentile(golden):
+    g = golden("percentile")
+    a = g["a"]
+    assert orc.percentile_linear(a[a > 0], 95) == g["p95_nonzero"]
+    assert orc.percentile_linear(a, 99) == g["p99"]
+    assert orc.percentile_linear(a, 1) == g["p1"]
+    assert orc.percentile_linear(a[a > 0].astype(np.float64), 95) == g["p95_f64"]
+
+
+@pytest.mark.parametrize("case", ["a", "b", "d", "e", "f"])
+def test_projection(golden, case):
+    g = golden("projection")
+    st = g[case + "_stack"]
+    kw = dict(a=dict(axes="TCZYX", reference_channel=0, airyscan=False),
+              b=dict(axes="CZYX", reference_channel=1, airyscan=True),
+              d=dict(axes="CZYX", reference_channel=0, min_z=0, max_z=9, airyscan=False, atoh_shift=-2),
+              e=dict(axes="CZYX", reference_channel=0, airyscan=False),
+              f=dict(axes="TCZYX", reference_channel=0, airyscan=False))[case]
+    tp = st[None] if kw["axes"].startswith("T") else st
+    axes = kw.pop("axes")
+    ref_ch = kw.pop("reference_channel")
+    proj, zmap = orc.time_point_surface_projection(tp.copy(), axes, ref_ch, z_map=True, **kw)
+    assert proj.dtype == np.float64 and zmap.dtype == np.int64
+    np.testing.assert_array_equal(zmap, g[case + "_zmap"])
+    np.testing.assert_array_equal(proj, g[case + "_proj"])
+
+
+def test_projection_no_channel_axis_error(golden):
+    g = golden("projection")
+    assert str(g["c_error"]) == "RuntimeError"
+    with pytest.raises(RuntimeError):
+        orc.time_point_surface_projection(np.zeros((4, 8, 8), np.uint16), "ZYX", 0, airyscan=False)
+
+
+def test_rank_filters(golden):
+    g = golden("rank_filters")
+    lab, img = g["lab"], g["img"]
+    cross = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    np.testing.assert_array_equal(orc.maximum_filter(lab, (5, 5), mode="constant"), g["max5_const"])
+    np.testing.assert_array_equal(orc.maximum_filter(lab, (3, 3), mode="constant"), g["max3_const"])
+    np.testing.assert_array_equal(orc.maximum_filter(lab, footprint=cross, mode="constant"), g["max_cross_const"])
+    np.testing.assert_array_equal(orc.minimum_filter(lab, footprint=cross, mode="constant"), g["min_cross_const"])
+    np.testing.assert_array_equal(orc.maximum_filter(img, 7), g["max7_reflect_f64"])
+    np.testing.assert_array_equal(orc.maximum_filter(img, 4), g["max4_reflect_f64"])
+    b = g["binimg"]
+    np.testing.assert_array_equal(orc.dilation(b, 5), g["dil5"])
+    np.testing.assert_array_equal(orc.erosion(b, 5), g["ero5"])
+    np.testing.assert_array_equal(orc.erosion(b, 7), g["ero7"])
+    np.testing.assert_array_equal(orc.dilation(img, 5), g["dil5_gray"])
+    np.testing.assert_array_equal(orc.erosion(img, 7), g["ero7_gray"])
+    closed = orc.erosion(orc.dilation(b, 5), 5)
+    np.testing.assert_array_equal(closed, g["closed_once"])
+    # closing is idempotent: 101 iterations == 1; pinned by the golden
+    np.testing.assert_array_equal(closed, g["closed_101"])
+    for blk in (3, 5):
+        np.testing.assert_array_equal(orc.threshold_local_generic_max(img, 0.03, blk), g["thrloc_b%d" % blk])
+
+
+def test_label(golden):
+    g = golden("label")
+    np.testing.assert_array_equal(orc.label4(g["bin"], 0)[0], g["label_bg0"])
+    np.testing.assert_array_equal(orc.label4(g["img255"], 255)[0], g["label_bg255"])
+    np.testing.assert_array_equal(orc.label4(g["multi"], 0)[0], g["label_multi_bg0"])
+    np.testing.assert_array_equal(orc.label4((g["bin"] != 0).astype(np.int32), 0)[0], g["ndi_label"])
+    np.testing.assert_array_equal(orc.label4(g["snake"], 0)[0], g["label_snake"])
+
+
+def test_watershed_pieces(golden):
+    g = golden("watershed")
+    np.testing.assert_array_equal(orc.local_minima(g["i2_blurred"]), g["i2_minima"])
+    np.testing.assert_array_equal(orc.label4(g["i2_minima"].astype(np.int32), 0)[0], g["i2_markers"])
+
+
+@pytest.mark.parametrize("case", ["ii", "iii", "iv", "v", "vi"])
+def test_watershed_flood(golden, case):
+    g = golden("watershed")
+    key = {"vi": "vi_boundary"}.get(case, case + "_img")
+    np.testing.assert_array_equal(orc.watershed(g[key]), g[case + "_labels"])
+
+
+def test_watershed_misc(golden):
+    g = golden("watershed")
+    np.testing.assert_array_equal(orc.watershed(g["ii_img"], watershed_line=False), g["ii_labels_nowsl"])
+    np.testing.assert_array_equal(orc.watershed(np.full((12, 14), 3.5)), g["vii_const_labels"])
+    np.testing.assert_array_equal(orc.watershed(g["vii_bowl"]), g["vii_bowl_labels"])
+
+
+def test_watershed_segmentation(golden):
+    g = golden("watershed")
+    np.testing.assert_array_equal(orc.watershed_segmentation(g["i_img"], 0.03, 3, 3), g["i_labels"])
+    np.testing.assert_array_equal(orc.watershed_segmentation(g["i2_img"], 0.03, 3, 3), g["i2_labels"])
+    np.testing.assert_array_equal(orc.watershed_segmentation(g["i2_img"], 0.2, 2, 4), g["i3_labels"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cellinfo(golden, tag):
+    g = golden("cellinfo")
+    lab = g[tag + "_labels"]
+    rp = orc.regionprops(lab)
+    present = rp["area"] > 0
+    np.testing.assert_array_equal(rp["label"][present], g[tag + "_rp_label"])
+    np.testing.assert_array_equal(rp["area"][present], g[tag + "_rp_area"])
+    np.testing.assert_allclose(rp["perimeter"][present], g[tag + "_rp_perimeter"], rtol=1e-13)
+    np.testing.assert_array_equal(rp["cy"][present], g[tag + "_rp_centroid-0"])
+    np.testing.assert_array_equal(rp["cx"][present], g[tag + "_rp_centroid-1"])
+    for k in range(4):
+        np.testing.assert_array_equal(rp["bbox"][present, k], g[tag + "_rp_bbox-%d" % k])
+    ci = orc.frame_cellinfo(lab)
+    np.testing.assert_array_equal(ci["area"], g[tag + "_area"])
+    np.testing.assert_array_equal(ci["valid"], g[tag + "_valid"])
+    np.testing.assert_array_equal(ci["n_neighbors"], g[tag + "_n_neighbors"])
+    nb = g[tag + "_neighbors"]
+    for i, s in enumerate(ci["neighbors"]):
+        assert sorted(s) == [int(v) for v in nb[i] if v > 0], i
+    np.testing.assert_array_equal(orc.contact_matrix(lab, ci["neighbors"]), g[tag + "_contact"])
+
+
+def test_update_labels(golden):
+    g = golden("cellinfo")
+    np.testing.assert_array_equal(orc.update_labels(g["u_in"]), g["u_out"])
+
+
+def test_celltypes_pins(golden):
+    g = golden("celltypes")
+    lab, inten = g["labels"], g["intensity"]
+    rp = orc.regionprops(lab, inten)
+    np.testing.assert_allclose(rp["intensity_mean"], g["mean"], rtol=1e-12)
+    p10 = np.array([orc.percentile_linear(inten[lab == i], 10) for i in range(1, lab.max() + 1)])
+    np.testing.assert_allclose(p10, g["p10"], rtol=1e-15)
+    assert orc.percentile_linear(inten, 99) == g["p99"]
+    blurred = orc.blur_image(inten, 7)
+    lm = np.abs(blurred - orc.maximum_filter(blurred, 7)) < 1e-6
+    np.testing.assert_array_equal(lm, g["local_maxima"])
+
+
+def test_unet_tail(golden):
+    g = golden("unet_tail")
+    labels, hc, boundary, closed = orc.closing_tail(g["p0"], thr=0.55)
+    np.testing.assert_array_equal(closed, g["closed"])
+    np.testing.assert_array_equal(hc, g["hc"])
+    np.testing.assert_array_equal(boundary, g["boundary"])
+    np.testing.assert_array_equal(labels, g["labels"])
+
+
+def test_tracking(golden):
+    g = golden("tracking")
+    assert bool(g["ok"])
+    labs = g["labels"]
+    tables = []
+    for f in range(labs.shape[0]):
+        ci = orc.frame_cellinfo(labs[f])
+        np.testing.assert_array_equal(ci["cx"], g["cx_%d" % f])
+        np.testing.assert_array_equal(ci["cy"], g["cy_%d" % f])
+        tables.append(ci)
+    drifts = np.zeros((3, 2))
+    drifts[1] = (0.5, -0.3)
+    drifts[2] = (0.5, -0.3)
+    ids = orc.track_simple(list(labs), tables, drifts)
+    for f in range(labs.shape[0]):
+        np.testing.assert_array_equal(ids[f], g["ids_%d" % f])

@@ -1,0 +1,396 @@
+#!/opt/conda/bin/python3.9
+"""Generate golden input/output vectors from the REFERENCE implementation.
+
+Run in the build container only:
+    /opt/conda/bin/python3.9 tools/make_goldens.py
+
+The reference (/root/reference, read-only) is imported with empty stub modules
+for its I/O-only dependencies that are absent here (aicsimageio, trackpy,
+tensorflow) and its own functions are called on seeded synthetic inputs.  The
+interpreter is the container's Anaconda tree (numpy 1.26.4, scipy 1.7.1,
+scikit-image 0.18.3) -- the only one that has scikit-image.  Only DATA (inputs
++ outputs) is written to tests/golden/*.npz; no reference source is copied.
+"""
+import os
+import sys
+import types
+import tempfile
+import warnings
+
+warnings.filterwarnings("ignore")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_stub("aicsimageio", AICSImage=object)
+_stub("aicsimageio.readers", czi_reader=None, bioformats_reader=None)
+_stub("aicsimageio.writers", ome_tiff_writer=None)
+_stub("trackpy")
+sys.path.insert(0, os.path.join(REF, "tissue_analyzing_tool"))
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import skimage  # noqa: E402
+import scipy.ndimage as ndi  # noqa: E402
+import skimage.morphology  # noqa: E402
+import skimage.segmentation  # noqa: E402
+import skimage.measure  # noqa: E402
+import basic_image_manipulations as bim  # noqa: E402  (reference)
+import surface_projection as sp  # noqa: E402  (reference)
+import tissue_info as ti  # noqa: E402  (reference)
+from tissue_image_processing_amd import synthetic  # noqa: E402
+
+VERSIONS = np.array([np.__version__, scipy.__version__, skimage.__version__])
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, versions=VERSIONS, **arrays)
+    print("wrote", path, {k: (v.shape, str(v.dtype)) for k, v in arrays.items()})
+
+
+def gold_gaussian():
+    rng = np.random.default_rng(11)
+    vol = (rng.poisson(100, (6, 40, 56)) + 2000 * rng.random((6, 40, 56)) ** 6).astype(np.float32)
+    out = {"vol_f32": vol}
+    for tag, sig in [("s05_1_1", (0.5, 1, 1)), ("s05_30_30", (0.5, 30, 30)), ("s1_2_2", (1, 2, 2))]:
+        out["out_" + tag] = bim.blur_image(vol, sig)
+    img = (rng.random((70, 90)) * 1000).astype(np.float64)
+    out["img_f64"] = img
+    out["out2d_s3"] = bim.blur_image(img, 3)
+    out["out2d_s7"] = bim.blur_image(img, 7)
+    img32 = img.astype(np.float32)
+    out["out2d_f32_s3"] = bim.blur_image(img32, 3)
+    # tiny axis shorter than the kernel radius (edge replication dominates)
+    tiny = rng.random((3, 5, 4)).astype(np.float32)
+    out["tiny_f32"] = tiny
+    out["tiny_out_s05_30_30"] = bim.blur_image(tiny, (0.5, 30, 30))
+    save("gaussian", **out)
+
+
+def gold_projection():
+    # (a) C=2, TCZYX, airyscan False, z_map
+    st = synthetic.make_stack(12, 96, 128, seed=3)
+    tp = st[None]  # (T=1,C,Z,Y,X)
+    proj, zmap = sp.time_point_surface_projection(tp.copy(), "TCZYX", 0, airyscan=False, z_map=True)
+    out = {"a_stack": st, "a_proj": proj, "a_zmap": zmap}
+    # (b) airyscan True (offset 10000), reference channel 1, CZYX axes
+    st_b = synthetic.make_stack(8, 64, 80, seed=4, offset=10000)
+    proj_b, zmap_b = sp.time_point_surface_projection(st_b.copy(), "CZYX", 1, airyscan=True, z_map=True)
+    out.update(b_stack=st_b, b_proj=proj_b, b_zmap=zmap_b)
+    # (c) no channel axis: the reference indexes image[reference_channel] on a (Z,Y,X) array and then blurs the
+    #     resulting 2-D slice with a 3-tuple sigma -> scipy raises RuntimeError.  Recorded as an error case.
+    st_c = synthetic.make_stack(9, 48, 64, seed=5, channels=1)[0]
+    try:
+        sp.time_point_surface_projection(st_c.copy(), "ZYX", 0, airyscan=False, z_map=False)
+        err_c = "none"
+    except Exception as e:
+        err_c = type(e).__name__
+    out.update(c_error=np.array(err_c))
+    # (d) atoh_shift != 0, max_z slicing, 3 channels
+    st_d = synthetic.make_stack(10, 40, 48, seed=6, channels=3)
+    proj_d, zmap_d = sp.time_point_surface_projection(st_d.copy(), "CZYX", 0, min_z=0, max_z=9, airyscan=False,
+                                                      z_map=True, atoh_shift=-2)
+    out.update(d_stack=st_d, d_proj=proj_d, d_zmap=zmap_d)
+    # (e) all-zero reference channel (empty non-zero selection branch)
+    st_e = synthetic.make_stack(6, 32, 32, seed=7)
+    st_e[0] = 0
+    proj_e, zmap_e = sp.time_point_surface_projection(st_e.copy(), "CZYX", 0, airyscan=False, z_map=True)
+    out.update(e_stack=st_e, e_proj=proj_e, e_zmap=zmap_e)
+    # (f) a larger frame, 512x512x10, BASELINE config[0] plumbing case
+    st_f = synthetic.make_stack(10, 160, 192, seed=8)
+    proj_f, zmap_f = sp.time_point_surface_projection(st_f[None].copy(), "TCZYX", 0, airyscan=False, z_map=True)
+    out.update(f_stack=st_f, f_proj=proj_f, f_zmap=zmap_f)
+    save("projection", **out)
+    return proj, proj_f
+
+
+def gold_rank_filters():
+    rng = np.random.default_rng(21)
+    lab = rng.integers(0, 40, (37, 53)).astype(np.int32)
+    lab[rng.random(lab.shape) < 0.3] = 0
+    lab[3:6, 4:9] = -1
+    img = rng.random((37, 53)) * 255
+    cross = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    out = {"lab": lab, "img": img}
+    out["max5_const"] = ndi.maximum_filter(lab, (5, 5), mode="constant")
+    out["max3_const"] = ndi.maximum_filter(lab, (3, 3), mode="constant")
+    out["max_cross_const"] = ndi.maximum_filter(lab, footprint=cross, mode="constant")
+    out["min_cross_const"] = ndi.minimum_filter(lab, footprint=cross, mode="constant")
+    out["max7_reflect_f64"] = ndi.maximum_filter(img, size=7)
+    out["max4_reflect_f64"] = ndi.maximum_filter(img, size=4)
+    binimg = (img > 180) * 255.0
+    k5 = np.ones((5, 5), np.uint8)
+    k7 = np.ones((7, 7), np.uint8)
+    out["binimg"] = binimg
+    out["dil5"] = skimage.morphology.dilation(binimg, k5)
+    out["ero5"] = skimage.morphology.erosion(binimg, k5)
+    out["ero7"] = skimage.morphology.erosion(binimg, k7)
+    out["dil5_gray"] = skimage.morphology.dilation(img, k5)
+    out["ero7_gray"] = skimage.morphology.erosion(img, k7)
+    closed = skimage.morphology.erosion(skimage.morphology.dilation(binimg, k5), k5)
+    c = closed
+    for _ in range(100):
+        c = skimage.morphology.erosion(skimage.morphology.dilation(c, k5), k5)
+    out["closed_once"] = closed
+    out["closed_101"] = c
+    from skimage.filters import threshold_local
+    for b in (3, 5):
+        out["thrloc_b%d" % b] = threshold_local(img, block_size=b, method="generic",
+                                                param=lambda a: 0.03 * np.max(a))
+    save("rank_filters", **out)
+
+
+def gold_label():
+    rng = np.random.default_rng(31)
+    a = (rng.random((45, 61)) > 0.45).astype(np.int64)
+    out = {"bin": a}
+    out["label_bg0"] = skimage.measure.label(a, connectivity=1, background=0)
+    img255 = np.where(a > 0, 0, 255).astype(np.uint8)
+    out["img255"] = img255
+    out["label_bg255"] = skimage.measure.label(img255, background=255, connectivity=1)
+    multi = rng.integers(0, 4, (33, 47)).astype(np.int32)
+    out["multi"] = multi
+    out["label_multi_bg0"] = skimage.measure.label(multi, connectivity=1, background=0)
+    out["ndi_label"] = ndi.label(a)[0].astype(np.int32)
+    # snake / spiral components stress union-find
+    sn = np.zeros((40, 40), np.int64)
+    for r in range(0, 40, 2):
+        sn[r, :] = 1
+        sn[r + 1, 0 if (r // 2) % 2 else 39] = 1
+    out["snake"] = sn
+    out["label_snake"] = skimage.measure.label(sn, connectivity=1, background=0)
+    save("label", **out)
+
+
+def gold_watershed(proj_small, proj_large):
+    out = {}
+    # (i) reference call on projection outputs (f64) with GUI defaults
+    zo = proj_small[0].T.copy()  # gui passes the transposed ZO projection
+    out["i_img"] = zo
+    out["i_labels"] = bim.watershed_segmentation(zo.copy(), 0.03, 3, 3)
+    zo2 = proj_large[0].copy()
+    out["i2_img"] = zo2
+    out["i2_labels"] = bim.watershed_segmentation(zo2.copy(), 0.03, 3, 3)
+    out["i3_labels"] = bim.watershed_segmentation(zo2.copy(), 0.2, 2, 4)
+    # intermediate products of case i2 for stage-wise checks
+    from skimage.filters import threshold_local
+    thr = threshold_local(zo2, block_size=3, method="generic", param=lambda a: 0.03 * np.max(a))
+    seg = zo2.copy()
+    seg[seg < thr] = 0
+    blurred = bim.blur_image(seg, 3)
+    out["i2_blurred"] = blurred
+    from skimage.morphology import local_minima
+    out["i2_minima"] = local_minima(blurred, connectivity=1).astype(np.uint8)
+    out["i2_markers"] = ndi.label(local_minima(blurred, connectivity=1))[0].astype(np.int32)
+    # (ii) smooth random landscape
+    rng = np.random.default_rng(41)
+    land = ndi.gaussian_filter(rng.random((90, 120)), 4)
+    out["ii_img"] = land
+    out["ii_labels"] = skimage.segmentation.watershed(land, watershed_line=True)
+    out["ii_labels_nowsl"] = skimage.segmentation.watershed(land, watershed_line=False)
+    # (iii) landscape with exact-zero plateaus and noise (stuck-pocket stress)
+    noisy = rng.random((80, 100))
+    noisy[noisy < 0.25] = 0
+    noisy = ndi.gaussian_filter(noisy, 1.0)
+    noisy[30:40, 20:50] = 0
+    out["iii_img"] = noisy
+    out["iii_labels"] = skimage.segmentation.watershed(noisy, watershed_line=True)
+    # (iv) raw white noise f64 (many tiny basins, many lines -> many stuck pixels)
+    wn = rng.random((64, 72))
+    out["iv_img"] = wn
+    out["iv_labels"] = skimage.segmentation.watershed(wn, watershed_line=True)
+    # (v) quantised image: heavy ties between non-marker pixels (FIFO/heap order matters)
+    q = np.round(ndi.gaussian_filter(rng.random((60, 70)), 2) * 40)
+    out["v_img"] = q
+    out["v_labels"] = skimage.segmentation.watershed(q, watershed_line=True)
+    # (vi) binary {0,255} boundary image as in prediction_local.py:191-194
+    prob = ndi.gaussian_filter(rng.random((96, 110)), 3)
+    hcb = (prob > np.percentile(prob, 70)) * 255.0
+    k5 = np.ones((5, 5), np.uint8)
+    closed = skimage.morphology.erosion(skimage.morphology.dilation(hcb, k5), k5)
+    hc = skimage.morphology.erosion(closed, np.ones((7, 7), np.uint8))
+    bound = closed - hc
+    boundary = skimage.morphology.dilation(bound, k5)
+    out["vi_hcb"] = hcb
+    out["vi_hc"] = hc
+    out["vi_boundary"] = boundary
+    out["vi_labels"] = skimage.segmentation.watershed(boundary, watershed_line=True)
+    # (vii) constant image and a 1-minimum image
+    const = np.full((12, 14), 3.5)
+    out["vii_const_labels"] = skimage.segmentation.watershed(const, watershed_line=True)
+    bowl = np.add.outer((np.arange(15) - 7.0) ** 2, (np.arange(17) - 8.0) ** 2)
+    out["vii_bowl"] = bowl
+    out["vii_bowl_labels"] = skimage.segmentation.watershed(bowl, watershed_line=True)
+    save("watershed", **out)
+    return out["i2_labels"], out["i_labels"]
+
+
+def _cells_table(tissue, frame):
+    ci = tissue.get_cells_info(frame)
+    n = ci.shape[0]
+    cols = {}
+    for k in ["area", "perimeter", "label", "cx", "cy", "n_neighbors", "valid", "type",
+              "bounding_box_min_row", "bounding_box_min_col", "bounding_box_max_row", "bounding_box_max_col",
+              "empty_cell"]:
+        cols[k] = np.asarray(ci[k].to_numpy(), dtype=np.float64)
+    # neighbours as padded matrix
+    maxn = max([len(s) for s in ci.neighbors] + [1])
+    nb = np.zeros((n, maxn), np.int64)
+    for i, s in enumerate(ci.neighbors):
+        ss = sorted(int(v) for v in s)
+        nb[i, :len(ss)] = ss
+    cols["neighbors"] = nb
+    return cols
+
+
+def gold_cellinfo(labels_a, labels_b):
+    tmp = tempfile.mkdtemp(prefix="tipgold_")
+    out = {}
+    for tag, lab in (("a", labels_a), ("b", labels_b)):
+        t = ti.Tissue(3, os.path.join(tmp, "movie_" + tag), ["zo", "atoh"])
+        t.set_labels(1, lab.copy(), reset_data=True)
+        t.calculate_frame_cellinfo(1)
+        cols = _cells_table(t, 1)
+        out[tag + "_labels"] = lab
+        for k, v in cols.items():
+            out[tag + "_" + k] = v
+        # contact matrix (C6)
+        out[tag + "_contact"] = t.calc_neighbors_contact_matrix(1)
+        # regionprops raw (C1)
+        props = skimage.measure.regionprops_table(lab, properties=["label", "area", "perimeter", "centroid", "bbox"])
+        for k, v in props.items():
+            out[tag + "_rp_" + k] = np.asarray(v)
+    # update_labels (C3): negative pixels replaced by 3x3 max
+    lab = labels_a.copy()
+    lab[10:14, 20:23] = -1
+    t = ti.Tissue(1, os.path.join(tmp, "movie_u"), ["zo"])
+    t.set_labels(1, lab.copy(), reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    out["u_in"] = lab
+    t.update_labels(1)
+    out["u_out"] = t.get_labels(1)
+    save("cellinfo", **out)
+
+
+def gold_tracking():
+    """T3: label-lookup tracker over 3 drifting frames (drift supplied via precomputed drifts)."""
+    tmp = tempfile.mkdtemp(prefix="tipgold_")
+    ny, nx, frames = 96, 120, 3
+    sites_t, is_hc = synthetic.make_movie_sites(ny, nx, frames, seed=9)
+    t = ti.Tissue(frames, os.path.join(tmp, "movie_t"), ["zo"], load_to_memory=True)
+    labs = []
+    for f in range(frames):
+        d1, d2, i1 = synthetic._two_nearest(sites_t[f], ny, nx)
+        membrane = np.exp(-((d2 - d1) ** 2) / 4.0)
+        lab = skimage.segmentation.watershed(ndi.gaussian_filter(membrane, 1.5), watershed_line=True)
+        labs.append(lab.astype(np.int32))
+    out = {}
+    # load_to_memory path keeps per-frame lists; fill them directly like load_data_to_memory would
+    for f in range(frames):
+        t.labels_list[f] = labs[f]
+    t.drifts[:] = 0
+    t.drifts[1] = (0.5, -0.3)
+    t.drifts[2] = (0.5, -0.3)
+    ok = True
+    try:
+        for f in range(frames):
+            t.set_labels(f + 1, labs[f].copy(), reset_data=False)
+            t.calculate_frame_cellinfo(f + 1)
+            t.cell_info_list[f] = t.cells_info.copy()
+        for _ in t.track_cells_iterator(1, frames):
+            pass
+    except Exception as e:  # reference cache plumbing differs between versions; record and fall through
+        print("tracking golden skipped:", repr(e))
+        ok = False
+    out["labels"] = np.stack(labs)
+    out["ok"] = np.array(ok)
+    if ok:
+        for f in range(frames):
+            ci = t.get_cells_info(f + 1)
+            out["ids_%d" % f] = ci.label.to_numpy().astype(np.int64)
+            out["cx_%d" % f] = ci.cx.to_numpy().astype(np.float64)
+            out["cy_%d" % f] = ci.cy.to_numpy().astype(np.float64)
+    save("tracking", **out)
+
+
+def gold_celltypes():
+    """C5 pins: per-label mean and percentile by direct numpy (calc_cell_types itself needs skimage>=0.19)."""
+    rng = np.random.default_rng(51)
+    land = ndi.gaussian_filter(rng.random((70, 80)), 3)
+    lab = skimage.segmentation.watershed(land, watershed_line=True).astype(np.int32)
+    inten = (rng.random(lab.shape) * 1000).astype(np.float64)
+    n = lab.max()
+    mean = np.array([inten[lab == i].mean() for i in range(1, n + 1)])
+    p10 = np.array([np.percentile(inten[lab == i], 10) for i in range(1, n + 1)])
+    p99 = np.percentile(inten, 99)
+    lm = ti.find_local_maxima(inten, window_size=7)
+    save("celltypes", labels=lab, intensity=inten, mean=mean, p10=p10, p99=np.array(p99), local_maxima=lm)
+
+
+def gold_unet_tail():
+    """U3-U5 non-NN tail of SegmentationPredictor.predict on a fake probability map (skimage called directly
+    with the call pattern of prediction_local.py:167-194; the class itself needs tensorflow)."""
+    rng = np.random.default_rng(61)
+    p0 = ndi.gaussian_filter(rng.random((72, 88)), 2.5)
+    p0 = (p0 - p0.min()) / (p0.max() - p0.min())
+    hcb = np.zeros(p0.shape)
+    hcb[p0 > 0.55] = 255
+    k5 = np.ones((5, 5), np.uint8)
+    d = skimage.morphology.dilation(hcb, k5)
+    e = skimage.morphology.erosion(d, k5)
+    for _ in range(100):
+        d = skimage.morphology.dilation(e, k5)
+        e = skimage.morphology.erosion(d, k5)
+    hc = skimage.morphology.erosion(e, np.ones((7, 7), np.uint8))
+    bound = e - hc
+    boundary = skimage.morphology.dilation(bound, k5)
+    ws = skimage.segmentation.watershed(boundary, watershed_line=True)
+    save("unet_tail", p0=p0, closed=e, hc=hc, boundary=boundary, labels=ws)
+
+
+def gold_weights():
+    """Gaussian tap weights exactly as this interpreter's scipy Python layer builds them (np.exp is not
+    correctly rounded and differs between numpy builds, so the taps are part of the golden environment)."""
+    from scipy.ndimage.filters import _gaussian_kernel1d
+    out = {}
+    for s in (0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 7.0, 30.0):
+        out["w_%g" % s] = _gaussian_kernel1d(s, 0, int(4.0 * s + 0.5))
+    save("weights", **out)
+
+
+def gold_percentile():
+    rng = np.random.default_rng(71)
+    a = rng.integers(0, 5000, 100003).astype(np.float32)
+    a[rng.random(a.size) < 0.2] = 0
+    nz = a[a > 0]
+    save("percentile", a=a, p95_nonzero=np.array(np.percentile(nz, 95)),
+         p99=np.array(np.percentile(a, 99)), p1=np.array(np.percentile(a, 1)),
+         p95_f64=np.array(np.percentile(nz.astype(np.float64), 95)))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gold_weights()
+    gold_gaussian()
+    gold_percentile()
+    pa, pf = gold_projection()
+    gold_rank_filters()
+    gold_label()
+    la, lb = gold_watershed(pa, pf)
+    gold_cellinfo(la, lb)
+    gold_celltypes()
+    gold_unet_tail()
+    gold_tracking()
+    print("done")
