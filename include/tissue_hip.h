@@ -1,0 +1,140 @@
+/*
+ * tissue_hip.h -- C-ABI of libtissue_hip.so (MI355X / gfx950 hot path).
+ *
+ * The reference (kasirershahartau/tissue_image_processing) is pure Python and has no
+ * native boundary of its own; each entry point below replaces the third-party call
+ * the reference makes at the cited line, so that the Python drop-in modules
+ * (tissue_image_processing_amd/{basic_image_manipulations,surface_projection,
+ * tissue_info,prediction_local}.py) can keep the reference's signatures and bind
+ * these symbols through ctypes.
+ *
+ * Conventions
+ *   - plain C types only; row-major contiguous arrays; explicit dims
+ *   - return 0 on success, negative tip_status on error; text via tip_last_error()
+ *   - `*_dev` variants take DEVICE pointers, run asynchronously on the calling
+ *     thread's stream and do not synchronise; the others take HOST pointers,
+ *     stage through device workspaces and return after the result is in `out`
+ *   - re-entrant: one HIP stream + workspace pool per calling thread
+ *   - float arithmetic reproduces scipy.ndimage bit for bit: double accumulation in
+ *     scipy's tap order, separately rounded multiply and add (no FMA contraction),
+ *     rounding to the array dtype after every axis pass
+ */
+#ifndef TISSUE_HIP_H
+#define TISSUE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIP_API __attribute__((visibility("default")))
+
+typedef enum {
+    TIP_OK = 0,
+    TIP_ERR_HIP = -1,        /* a HIP runtime call failed */
+    TIP_ERR_ARG = -2,        /* bad argument (ValueError in the Python mirror) */
+    TIP_ERR_NOMEM = -3,
+    TIP_ERR_INDEX = -4,      /* the reference would raise IndexError (sp.py:62,68 clip upper bound) */
+    TIP_ERR_UNSUPPORTED = -5,
+    TIP_ERR_OVERFLOW = -6    /* caller-provided capacity too small */
+} tip_status;
+
+/* ---- lifecycle / plumbing ------------------------------------------------------------------- */
+TIP_API int tip_init(int device);                 /* bind the calling thread to `device` (default 0) */
+TIP_API int tip_shutdown(void);                   /* free this thread's stream + workspaces */
+TIP_API int tip_last_error(char *buf, size_t n);  /* copy this thread's last error text */
+TIP_API int tip_device_count(void);
+TIP_API int tip_version(void);
+TIP_API int tip_malloc(void **dptr, size_t bytes);
+TIP_API int tip_free(void *dptr);
+TIP_API int tip_memcpy_h2d(void *dst, const void *src, size_t bytes);
+TIP_API int tip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+TIP_API int tip_memset(void *dst, int value, size_t bytes);
+TIP_API int tip_sync(void);                       /* wait for this thread's stream */
+
+/* per-kernel timing with HIP events on the library's own stream (bench.py roofline leg) */
+TIP_API int tip_prof_enable(int on);
+TIP_API int tip_prof_reset(void);
+/* writes lines "name count total_ms\n" ; returns number of bytes needed */
+TIP_API int tip_prof_report(char *buf, size_t n);
+
+/* ---- separable Gaussian: scipy.ndimage.gaussian_filter(mode='nearest') ---------------------- */
+/* replaces bim.py:389 (blur_image), called from sp.py:37,55,70,71 and ti.py:142.                */
+/* `taps` are scipy's _gaussian_kernel1d values (length 2*int(4*sigma+0.5)+1, symmetric); an axis */
+/* with n==0 is skipped (scipy skips sigma<=1e-15).  dtype: 0=float32, 1=float64.               */
+TIP_API int tip_gaussian_taps(double sigma, double truncate, double *taps, int cap); /* libm exp; returns n */
+TIP_API int tip_correlate1d_dev(const void *in, void *out, int dtype, int z, int y, int x, int axis,
+                                const double *taps_host, int n);
+TIP_API int tip_gaussian3d_w(const void *in, void *out, int dtype, int z, int y, int x,
+                             const double *tz, int nz, const double *ty, int ny, const double *tx, int nx);
+TIP_API int tip_gaussian3d_dev_w(const void *in, void *out, int dtype, int z, int y, int x,
+                                 const double *tz, int nz, const double *ty, int ny, const double *tx, int nx);
+TIP_API int tip_gaussian3d_f32(const float *in, float *out, int z, int y, int x,
+                               double sz, double sy, double sx, double truncate);
+TIP_API int tip_gaussian2d_f64(const double *in, double *out, int y, int x, double sy, double sx, double truncate);
+
+/* ---- surface projection: sp.py:17-85 (bin_size==1, build_manifold=False path) --------------- */
+/* czyx: uint16 (C,Z,Y,X).  [zlo,zhi) is the z slice sp.py:30-31 takes when max_z>0 (else 0,Z).   */
+/* taps: scipy taps for sigma 0.5 (5), 1 (9), 2 (17), 30 (241); pass NULL to have them built with */
+/* libm.  proj: float64 (C,Y,X) (sp.py:74 np.zeros -> float64); zmap: int64 (Y,X) = min_z+argmax. */
+TIP_API int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z,
+                            int ref_ch, int airyscan, int atoh_shift,
+                            const double *t05, const double *t1, const double *t2, const double *t30,
+                            double *proj, int64_t *zmap);
+TIP_API int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z,
+                                int ref_ch, int airyscan, int atoh_shift,
+                                const double *t05, const double *t1, const double *t2, const double *t30,
+                                double *proj, int64_t *zmap);
+
+/* ---- rank filters ---------------------------------------------------------------------------- */
+/* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */
+/* skimage.morphology.erosion/dilation with a flat footprint (pl.py:170-193).                     */
+/* footprint_kind: 0 = full ky x kx rectangle, 1 = 3x3 cross without centre ([[0,1,0],[1,0,1],[0,1,0]]). */
+/* border_mode: 0 = constant 0, 1 = reflect.  is_max: 1 max / 0 min.                              */
+TIP_API int tip_rankfilter2d(const void *in, void *out, int dtype /*1=f64, 2=i32*/, int y, int x, int ky, int kx,
+                             int footprint_kind, int border_mode, int is_max);
+TIP_API int tip_rankfilter2d_dev(const void *in, void *out, int dtype, int y, int x, int ky, int kx,
+                                 int footprint_kind, int border_mode, int is_max);
+/* bim.py:464-473: thr = imgthresh*max_filter(img, block, reflect) ; out = img < thr ? 0 : img (float64) */
+TIP_API int tip_local_threshold_f64_dev(const double *img, double *out, int y, int x, double imgthresh, int block);
+
+/* ---- connected components: skimage.measure.label(connectivity=1) (ti.py:2922,3470) ----------- */
+/* equal-valued 4-neighbours are connected, `bg` pixels -> 0, labels 1..n in raster order of the  */
+/* component's first pixel.  Also scipy.ndimage.label on a boolean image (watershed markers).     */
+TIP_API int tip_label4_i32(const int32_t *in, int32_t bg, int32_t *out, int y, int x, int32_t *n_labels);
+TIP_API int tip_label4_i32_dev(const int32_t *in, int32_t bg, int32_t *out, int y, int x, int32_t *n_labels_host);
+
+/* ---- watershed: skimage.segmentation.watershed(markers=None, connectivity=1) (bim.py:475, pl.py:194) */
+/* markers = label(local_minima(img)).  flags (out, may be NULL): bit0 = value ties between        */
+/* non-marker neighbours were met (FIFO order of the serial flood then not reproduced bit for bit). */
+TIP_API int tip_watershed_f64(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags);
+TIP_API int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host);
+/* bim.py:446-476 as one device pipeline: local threshold -> Gaussian(sigma) -> watershed          */
+TIP_API int tip_watershed_segmentation_f64_dev(const double *img, int32_t *labels, int y, int x, double imgthresh,
+                                               const double *taps, int ntaps, int block, int32_t *flags_host);
+
+/* ---- cell tables: regionprops_table + find_neighbors (ti.py:880-909,1815-1842) --------------- */
+/* SoA outputs over labels 1..n: area, bbox(min_row,min_col,max_row+1,max_col+1), coordinate sums  */
+/* (centroid = sum/area), perimeter code counts pc[3*l+{0,1,2}] (weights 1, sqrt2, (1+sqrt2)/2),   */
+/* optional intensity sums.                                                                        */
+TIP_API int tip_regionprops_i32(const int32_t *labels, const double *intensity /*nullable*/, int y, int x, int n,
+                                int64_t *area, int64_t *bbox4, int64_t *sumy, int64_t *sumx, int64_t *pc3,
+                                double *isum /*nullable*/);
+TIP_API int tip_regionprops_i32_dev(const int32_t *labels, const double *intensity, int y, int x, int n,
+                                    int64_t *area, int64_t *bbox4, int64_t *sumy, int64_t *sumx, int64_t *pc3,
+                                    double *isum);
+/* unique (hi,lo) pairs: a pixel labelled lo>0 whose zero-padded 5x5 maximum is hi != lo           */
+TIP_API int tip_neighbor_pairs_i32(const int32_t *labels, int y, int x, int32_t *pairs, int64_t cap, int64_t *n_pairs);
+TIP_API int tip_neighbor_pairs_i32_dev(const int32_t *labels, int y, int x, int32_t *pairs_dev, int64_t cap,
+                                       int64_t *n_pairs_host);
+/* Tissue.update_labels (ti.py:2967-2970): negatives take the zero-padded 3x3 maximum              */
+TIP_API int tip_update_labels_i32(int32_t *labels, int y, int x);
+/* Tissue.get_trackking_labels (ti.py:4021-4028): out[p] = lut[labels[p]] (lut[0] = 0)              */
+TIP_API int tip_lut_gather_i32(const int32_t *labels, const int64_t *lut, int64_t n_lut, int64_t *out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

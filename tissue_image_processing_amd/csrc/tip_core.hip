@@ -1,0 +1,305 @@
+// tip_core.hip -- context, memory, error and profiling plumbing of libtissue_hip.so
+#include "tip_internal.h"
+#include <cmath>
+#include <map>
+#include <mutex>
+
+namespace tip {
+
+static thread_local Ctx *g_ctx = nullptr;
+static thread_local int g_requested_device = 0;
+
+static int ctx_create(int device)
+{
+    Ctx *c = new Ctx();
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        c->err = std::string("hipSetDevice failed: ") + hipGetErrorString(e);
+        g_ctx = c;
+        return TIP_ERR_HIP;
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        c->err = std::string("hipStreamCreate failed: ") + hipGetErrorString(e);
+        c->stream = nullptr;
+        g_ctx = c;
+        return TIP_ERR_HIP;
+    }
+    g_ctx = c;
+    return TIP_OK;
+}
+
+Ctx &ctx()
+{
+    if (!g_ctx) ctx_create(g_requested_device);
+    return *g_ctx;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx().err = buf;
+    return code;
+}
+
+void *ws_alloc(size_t bytes)
+{
+    Ctx &c = ctx();
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < c.pool.size(); i++)
+        if (!c.pool[i].used && c.pool[i].bytes >= bytes && (best < 0 || c.pool[i].bytes < c.pool[best].bytes))
+            best = (int)i;
+    if (best >= 0 && c.pool[best].bytes <= 2 * bytes + (1 << 20)) {
+        c.pool[best].used = true;
+        return c.pool[best].p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // release cached free blocks and retry once
+        for (auto &b : c.pool)
+            if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            fail(TIP_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    c.pool.push_back({p, bytes, true});
+    return p;
+}
+
+void ws_free(void *p)
+{
+    Ctx &c = ctx();
+    for (auto &b : c.pool)
+        if (b.p == p) { b.used = false; return; }
+}
+
+void prof_begin(const char *name)
+{
+    Ctx &c = ctx();
+    if (!c.prof) return;
+    ProfRec r;
+    r.name = name;
+    if (c.free_events.size() >= 2) {
+        r.e0 = c.free_events.back(); c.free_events.pop_back();
+        r.e1 = c.free_events.back(); c.free_events.pop_back();
+    } else {
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+    }
+    (void)hipEventRecord(r.e0, c.stream);
+    c.recs.push_back(r);
+}
+
+void prof_end()
+{
+    Ctx &c = ctx();
+    if (!c.prof) return;
+    (void)hipEventRecord(c.recs.back().e1, c.stream);
+}
+
+int make_taps(Taps &t, const double *w, int n)
+{
+    if (n <= 0 || n > 255 || !(n & 1)) return fail(TIP_ERR_ARG, "tap count %d must be odd and <= 255", n);
+    for (int i = 1; i <= n / 2; i++)
+        if (fabs(w[n / 2 + i] - w[n / 2 - i]) > 2.220446049250313e-16)
+            return fail(TIP_ERR_UNSUPPORTED, "only symmetric kernels (scipy's symmetric correlate1d branch)");
+    memset(&t, 0, sizeof t);
+    for (int i = 0; i < n; i++) t.w[i] = w[i];
+    t.n = n;
+    return TIP_OK;
+}
+
+// numpy's pairwise float64 sum, so that phi/phi.sum() (scipy/ndimage/filters.py:_gaussian_kernel1d) matches
+static double np_pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (long i = 0; i < n; i++) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+int libm_taps(double sigma, double truncate, double *w, int cap)
+{
+    long radius = (long)(truncate * sigma + 0.5);
+    long n = 2 * radius + 1;
+    if (n > cap) return -1;
+    double s2 = sigma * sigma;
+    for (long i = 0; i < n; i++) {
+        double x = (double)(i - radius);
+        w[i] = exp(-0.5 / s2 * (x * x));
+    }
+    double sum = np_pairwise_sum(w, n);
+    for (long i = 0; i < n; i++) w[i] = w[i] / sum;
+    return (int)n;
+}
+
+}  // namespace tip
+
+using namespace tip;
+
+extern "C" {
+
+int tip_version(void) { return 100; }
+
+int tip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tip_init(int device)
+{
+    if (g_ctx) {
+        if (g_ctx->device == device && g_ctx->stream) return TIP_OK;
+        tip_shutdown();
+    }
+    g_requested_device = device;
+    int rc = ctx_create(device);
+    return rc;
+}
+
+int tip_shutdown(void)
+{
+    if (!g_ctx) return TIP_OK;
+    Ctx *c = g_ctx;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->pool)
+        if (b.p) (void)hipFree(b.p);
+    for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto &e : c->free_events) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    g_ctx = nullptr;
+    return TIP_OK;
+}
+
+int tip_last_error(char *buf, size_t n)
+{
+    if (!buf || !n) return TIP_ERR_ARG;
+    const std::string &e = ctx().err;
+    snprintf(buf, n, "%s", e.c_str());
+    return TIP_OK;
+}
+
+int tip_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return fail(TIP_ERR_ARG, "tip_malloc: null out pointer");
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return TIP_OK;
+}
+
+int tip_free(void *dptr)
+{
+    if (!dptr) return TIP_OK;
+    Ctx &c = ctx();
+    if (c.stream) TIP_HIP(hipStreamSynchronize(c.stream));
+    TIP_HIP(hipFree(dptr));
+    return TIP_OK;
+}
+
+int tip_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_memset(void *dst, int value, size_t bytes)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipMemsetAsync(dst, value, bytes, c.stream));
+    return TIP_OK;
+}
+
+int tip_sync(void)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_prof_enable(int on)
+{
+    ctx().prof = on != 0;
+    return TIP_OK;
+}
+
+int tip_prof_reset(void)
+{
+    Ctx &c = ctx();
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    for (auto &r : c.recs) { c.free_events.push_back(r.e0); c.free_events.push_back(r.e1); }
+    c.recs.clear();
+    return TIP_OK;
+}
+
+int tip_prof_report(char *buf, size_t n)
+{
+    Ctx &c = ctx();
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    std::map<std::string, std::pair<long, double>> agg;
+    std::vector<std::string> order;
+    for (auto &r : c.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        auto it = agg.find(r.name);
+        if (it == agg.end()) { agg[r.name] = {1, (double)ms}; order.push_back(r.name); }
+        else { it->second.first++; it->second.second += ms; }
+    }
+    std::string s;
+    char line[256];
+    for (auto &k : order) {
+        snprintf(line, sizeof line, "%s %ld %.6f\n", k.c_str(), agg[k].first, agg[k].second);
+        s += line;
+    }
+    if (buf && n) snprintf(buf, n, "%s", s.c_str());
+    return (int)s.size() + 1;
+}
+
+int tip_gaussian_taps(double sigma, double truncate, double *taps, int cap)
+{
+    if (!taps || sigma <= 0) return fail(TIP_ERR_ARG, "tip_gaussian_taps: bad arguments");
+    int n = libm_taps(sigma, truncate, taps, cap);
+    if (n < 0) return fail(TIP_ERR_OVERFLOW, "tip_gaussian_taps: capacity %d too small", cap);
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// tip_project.hip -- time_point_surface_projection (sp.py:17-85) as a device pipeline.
+//
+//   P1  uint16 -> float32, airyscan offset (sp.py:26-29)            fused into every reader of the stack
+//   P2  95th percentile of the non-zero reference voxels + clip     exact 65536-bin histogram (sp.py:32-36)
+//   P3  Gaussian (0.5,1,1)  (sp.py:37)                              exact scipy-order correlate passes
+//   P4  Gaussian (0.5,30,30) score (sp.py:55)                       long-kernel passes (tip_corr.h)
+//   P5  argmax over z, first maximum (sp.py:61)
+//   P6/P7 one-hot mask + Gaussian (1,2,2) (sp.py:62-71)             z pass = ZxZ table, y pass from the z-map,
+//   P8  per-channel max_z(image * mask) -> float64 (sp.py:72-81)    x pass fused with the weighted z-max
+#include "tip_corr.h"
+
+namespace tip {
+
+int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
+
+struct ClipInfo {
+    double p95d;
+    float p95;
+    int has;
+};
+
+// ---- P2: histogram of the (offset-corrected) reference channel -----------------------------------------
+// Each 1024-thread block owns 32768 consecutive voxels and a private 65536-bin LDS histogram of 16-bit
+// counters packed two per dword (a block can never overflow 16 bits), flushed with global atomics.
+constexpr int HIST_PER_BLOCK = 32768;
+__global__ void __launch_bounds__(1024) k_hist_u16(const uint16_t *__restrict__ in, long n, int airy,
+                                                   unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned int h[32768];
+    for (int i = threadIdx.x; i < 32768; i += 1024) h[i] = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * HIST_PER_BLOCK;
+    for (int k = 0; k < HIST_PER_BLOCK / (1024 * 8); ++k) {
+        const long i0 = base + ((long)k * 1024 + threadIdx.x) * 8;
+        if (i0 + 8 <= n && ((((uintptr_t)(in + i0)) & 15) == 0)) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + i0);
+            const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    int val = (int)((w[j] >> (16 * s)) & 0xffffu);
+                    if (airy) { val -= 10000; if (val < 0) val = 0; }
+                    atomicAdd(&h[val >> 1], 1u << (16 * (val & 1)));
+                }
+            }
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                if (i0 + j < n) {
+                    int val = in[i0 + j];
+                    if (airy) { val -= 10000; if (val < 0) val = 0; }
+                    atomicAdd(&h[val >> 1], 1u << (16 * (val & 1)));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32768; i += 1024) {
+        const unsigned int c = h[i];
+        if (c & 0xffffu) atomicAdd(&hist[2 * i], (unsigned long long)(c & 0xffffu));
+        if (c >> 16) atomicAdd(&hist[2 * i + 1], (unsigned long long)(c >> 16));
+    }
+}
+
+// np.percentile(nonzero, 95) with numpy 1.26 arithmetic (see oracle.percentile_linear): one block.
+__global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long *__restrict__ hist, ClipInfo *out)
+{
+    __shared__ unsigned long long part[1024];
+    unsigned long long s = 0;
+    for (int b = threadIdx.x * 64; b < threadIdx.x * 64 + 64; ++b)
+        if (b > 0) s += hist[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long n = 0;
+    for (int i = 0; i < 1024; ++i) n += part[i];
+    if (n == 0) {
+        out->has = 0; out->p95 = 0.f; out->p95d = 0.0;
+        return;
+    }
+    const double quant = 95.0 / 100.0;
+    const double virt = (double)n * quant + (1.0 + quant * (1.0 - 1.0 - 1.0)) - 1.0;
+    double fl = floor(virt);
+    const double gamma = virt - fl;
+    long long prev = (long long)fl;
+    if (prev < 0) prev = 0;
+    if (prev > (long long)n - 1) prev = (long long)n - 1;
+    long long next = prev + 1;
+    if (next > (long long)n - 1) next = (long long)n - 1;
+    // value at 0-based rank k among non-zero voxels
+    auto value_at = [&](long long k) -> int {
+        unsigned long long cum = 0;
+        int chunk = 0;
+        for (; chunk < 1024; ++chunk) {
+            if (cum + part[chunk] > (unsigned long long)k) break;
+            cum += part[chunk];
+        }
+        for (int b = chunk * 64; b < chunk * 64 + 64; ++b) {
+            if (b == 0) continue;
+            cum += hist[b];
+            if (cum > (unsigned long long)k) return b;
+        }
+        return 65535;
+    };
+    const float lo = (float)value_at(prev), hi = (float)value_at(next);
+    const double diff = (double)(hi - lo);
+    double res = (double)lo + diff * gamma;
+    if (gamma >= 0.5) res = (double)hi - diff * (1.0 - gamma);
+    out->p95d = res;
+    out->p95 = (float)res;  // numpy 1.x value-based casting: compared and assigned as float32 (sp.py:36)
+    out->has = 1;
+}
+
+// ---- P1+P2 fused reader of the reference channel ----------------------------------------------------------
+struct LoadU16Clip {
+    const uint16_t *p;
+    long sz, sy;
+    int airy;
+    const ClipInfo *clip;
+    __device__ __forceinline__ double operator()(int z, int y, int x) const
+    {
+        float f = (float)p[z * sz + y * sy + x];
+        if (airy) { f -= 10000.f; if (f < 0.f) f = 0.f; }
+        if (clip->has && f > clip->p95) f = clip->p95;
+        return (double)f;
+    }
+};
+
+// ---- P5: first-maximum argmax over z ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_argmax_z(const float *__restrict__ score, int Z, long P, int min_z,
+                                                  int atoh_shift, int32_t *__restrict__ zsel,
+                                                  int32_t *__restrict__ zsel_atoh, int64_t *__restrict__ zmap,
+                                                  int *__restrict__ err)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float best = score[p];
+    int bi = 0;
+    for (int z = 1; z < Z; ++z) {
+        const float s = score[(long)z * P + p];
+        if (s > best) { best = s; bi = z; }
+    }
+    const int cz = min_z + bi;               // sp.py:61
+    if (zmap) zmap[p] = cz;
+    int ca = cz;
+    if (atoh_shift != 0) {                   // sp.py:62 np.clip(chosen_z + shift, 0, Z)  (upper bound Z, sic)
+        ca = cz + atoh_shift;
+        ca = ca < 0 ? 0 : (ca > Z ? Z : ca);
+    }
+    if (cz >= Z || ca >= Z) {                // the reference's fancy index would raise IndexError (sp.py:68-69)
+        atomicOr(err, 1);
+        zsel[p] = cz >= Z ? Z - 1 : cz;
+        zsel_atoh[p] = ca >= Z ? Z - 1 : ca;
+        return;
+    }
+    zsel[p] = cz;
+    zsel_atoh[p] = ca;
+}
+
+__global__ void k_identity(float *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * n) out[i] = (i / n == i % n) ? 1.f : 0.f;
+}
+
+// ---- P6/P7: the z pass of a one-hot column is a table lookup -----------------------------------------------------
+struct LoadMaskTable {
+    const float *T;       // T[z*Zs + z0] = z-blurred one-hot(z0) at z
+    const int32_t *zsel;  // (Y,X) chosen plane
+    int Zs;
+    long X;
+    __device__ __forceinline__ double operator()(int z, int y, int x) const
+    {
+        return (double)T[z * Zs + zsel[(long)y * X + x]];
+    }
+};
+
+// ---- P7 x pass + P8 weighted z-max, all channels in one sweep ---------------------------------------------------
+// ymask: (Zs,Y,X) float32 after the z and y passes.  For every pixel: for each z, finish the x pass (exact
+// scipy order), round to float32, multiply with the float32 image value and keep the per-channel maximum.
+// chan_mask selects which channels this launch writes (reference vs. atoh-shifted mask, sp.py:75-79).
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_xpass_wmax(const float *__restrict__ ymask, const uint16_t *__restrict__ img,
+                                                    int C, int Zfull, int zlo, int Zs, int Y, int X, int airy,
+                                                    unsigned chan_mask, Taps taps, double *__restrict__ proj)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= X) return;
+    const int r = taps.n >> 1;
+    const long P = (long)Y * X;
+    float mx[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) mx[c] = 0.f;
+    for (int z = 0; z < Zs; ++z) {
+        const float *row = ymask + (long)z * P + (long)y * X;
+        double tmp = (double)row[x] * taps.w[r];
+        for (int d = r; d >= 1; --d) {
+            const float a = row[clampi(x - d, 0, X - 1)], b = row[clampi(x + d, 0, X - 1)];
+            tmp += ((double)a + (double)b) * taps.w[r - d];
+        }
+        const float m = (float)tmp;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < C && ((chan_mask >> c) & 1u)) {
+                float v = (float)img[((long)c * Zfull + zlo + z) * P + (long)y * X + x];
+                if (airy) { v -= 10000.f; if (v < 0.f) v = 0.f; }
+                const float pr = v * m;
+                // np.max over z of a float32 array; first z initialises
+                mx[c] = z == 0 ? pr : (pr > mx[c] ? pr : mx[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C && ((chan_mask >> c) & 1u)) proj[(long)c * P + (long)y * X + x] = (double)mx[c];
+}
+
+static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
+{
+    double buf[256];
+    if (!given) {
+        int n = libm_taps(sigma, 4.0, buf, 255);
+        if (n != expect) return fail(TIP_ERR_ARG, "internal: tap count %d != %d", n, expect);
+        given = buf;
+    }
+    return make_taps(t, given, expect);
+}
+
+int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int zhi, int min_z, int ref_ch,
+                int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                const double *t30, double *proj, int64_t *zmap)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!czyx || !proj) return fail(TIP_ERR_ARG, "project: null pointer");
+    if (C < 1 || C > 8) return fail(TIP_ERR_ARG, "project: 1..8 channels supported (got %d)", C);
+    if (ref_ch < 0 || ref_ch >= C) return fail(TIP_ERR_INDEX, "project: reference_channel %d out of range", ref_ch);
+    if (zlo < 0 || zhi > Z || zhi <= zlo) return fail(TIP_ERR_ARG, "project: bad z range [%d,%d) of %d", zlo, zhi, Z);
+    if (Y < 1 || X < 1 || Y > 65535) return fail(TIP_ERR_ARG, "project: bad frame size %dx%d", Y, X);
+    const int Zs = zhi - zlo;
+    const long P = (long)Y * X, V = (long)Zs * P;
+    Taps k05, k1, k2, k30;
+    int rc;
+    if ((rc = resolve_taps(t05, 0.5, 5, k05)) || (rc = resolve_taps(t1, 1.0, 9, k1)) ||
+        (rc = resolve_taps(t2, 2.0, 17, k2)) || (rc = resolve_taps(t30, 30.0, 241, k30)))
+        return rc;
+
+    WsGuard ws;
+    float *A = ws.get<float>(V), *B = ws.get<float>(V);
+    unsigned long long *hist = ws.get<unsigned long long>(65536);
+    ClipInfo *clip = ws.get<ClipInfo>(1);
+    int32_t *zsel = ws.get<int32_t>(P), *zsel_a = ws.get<int32_t>(P);
+    float *ident = ws.get<float>((size_t)Zs * Zs), *table = ws.get<float>((size_t)Zs * Zs);
+    int *err = ws.get<int>(1);
+    if (!A || !B || !hist || !clip || !zsel || !zsel_a || !ident || !table || !err) return TIP_ERR_NOMEM;
+
+    const uint16_t *ref = czyx + ((long)ref_ch * Z + zlo) * P;
+    TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
+    TIP_HIP(hipMemsetAsync(err, 0, sizeof(int), c.stream));
+    TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, ref, V, airyscan, hist);
+    TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip);
+
+    // P3: (0.5, 1, 1)
+    {
+        LoadU16Clip ld{ref, P, (long)X, airyscan, clip};
+        dim3 grid(cdiv(X, 256), Y, Zs), block(256);
+        TIP_LAUNCH("corr_z_u16clip", (k_corr_generic<float, 0, LoadU16Clip>), grid, block, 0, ld, A, Zs, Y, X, k05);
+    }
+    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 1, k1, 0))) return rc;
+    if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 2, k1, 0))) return rc;
+    // P4: (0.5, 30, 30)
+    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 0, k05, 0))) return rc;
+    if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
+    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
+    // P5
+    TIP_LAUNCH("argmax_z", k_argmax_z, dim3(cdiv(P, 256)), dim3(256), 0, B, Zs, P, min_z, atoh_shift, zsel, zsel_a,
+               zmap, err);
+    // P6/P7 z pass as a Zs x Zs table (sigma 1 -> 9 taps), built with the same correlate kernel
+    TIP_LAUNCH("identity", k_identity, dim3(cdiv((long)Zs * Zs, 256)), dim3(256), 0, ident, Zs);
+    if ((rc = correlate1d_dev(ident, table, 0, Zs, Zs, 1, 0, k1, 1))) return rc;
+
+    const unsigned all = (1u << C) - 1u;
+    for (int pass = 0; pass < (atoh_shift != 0 ? 2 : 1); ++pass) {
+        const int32_t *sel = pass == 0 ? zsel : zsel_a;
+        unsigned cm = atoh_shift == 0 ? all : (pass == 0 ? (1u << ref_ch) : (all & ~(1u << ref_ch)));
+        if (!cm) continue;
+        LoadMaskTable ld{table, sel, Zs, (long)X};
+        dim3 grid(cdiv(X, 256), Y, Zs), block(256);
+        TIP_LAUNCH("mask_ypass", (k_corr_generic<float, 1, LoadMaskTable>), grid, block, 0, ld, A, Zs, Y, X, k2);
+        TIP_LAUNCH("xpass_wmax", (k_xpass_wmax<8>), dim3(cdiv(X, 256), Y), dim3(256), 0, A, czyx, C, Z, zlo, Zs, Y, X,
+                   airyscan, cm, k2, proj);
+    }
+    if (min_z > 0 || atoh_shift > 0) {
+        int h = 0;
+        TIP_HIP(hipMemcpyAsync(&h, err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        TIP_HIP(hipStreamSynchronize(c.stream));
+        if (h)
+            return fail(TIP_ERR_INDEX, "chosen z index out of bounds for the %d-plane mask (min_z=%d, atoh_shift=%d): "
+                                       "the reference raises IndexError here (sp.py:62,68-69)", Zs, min_z, atoh_shift);
+    }
+    return TIP_OK;
+}
+
+}  // namespace tip
+
+using namespace tip;
+
+extern "C" {
+
+int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                        int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                        const double *t30, double *proj, int64_t *zmap)
+{
+    return project_dev(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                    int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                    const double *t30, double *proj, int64_t *zmap)
+{
+    Ctx &cx = ctx();
+    if (!cx.stream) return TIP_ERR_HIP;
+    if (!czyx || !proj) return fail(TIP_ERR_ARG, "tip_project_u16: null pointer");
+    if (c < 1 || z < 1 || y < 1 || x < 1) return fail(TIP_ERR_ARG, "tip_project_u16: empty stack");
+    const size_t nin = (size_t)c * z * y * x, P = (size_t)y * x;
+    WsGuard ws;
+    uint16_t *din = ws.get<uint16_t>(nin);
+    double *dproj = ws.get<double>((size_t)c * P);
+    int64_t *dz = ws.get<int64_t>(P);
+    if (!din || !dproj || !dz) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(din, czyx, nin * 2, hipMemcpyHostToDevice, cx.stream));
+    int rc = project_dev(din, c, z, y, x, zlo, zhi, min_z, ref_ch, airyscan, atoh_shift, t05, t1, t2, t30, dproj, dz);
+    if (rc) return rc;
+    TIP_HIP(hipMemcpyAsync(proj, dproj, (size_t)c * P * 8, hipMemcpyDeviceToHost, cx.stream));
+    if (zmap) TIP_HIP(hipMemcpyAsync(zmap, dz, P * 8, hipMemcpyDeviceToHost, cx.stream));
+    TIP_HIP(hipStreamSynchronize(cx.stream));
+    return TIP_OK;
+}
+
+}  // extern "C"
