@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end frames/s of the per-frame confocal-stack hot path on MI355X.
+
+One "step" = one pass of the hot path over one synthetic 2048x2048x30 (C=2, uint16) frame that is already
+resident in HBM: surface projection (sp.py:17-85) -> watershed_segmentation (bim.py:446-476) -> cell tables
+(ti.py:880-909).  One process per GPU; frames are independent units, so N GPUs process N frames per step with no
+data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6   # MI355X datasheet FP64 vector (spec); FP32 vector is 157.3 TF in the guide
+
+
+def algorithmic_bytes(kernel, C, Z, Y, X):
+    """Compulsory HBM bytes per launch (logical input read once + logical output written once), SURVEY.md 8(d)."""
+    V, P = Z * Y * X, Y * X
+    table = {
+        "hist_u16": V * 2,
+        "corr_z_u16clip": V * 2 + V * 4,
+        "corr_generic_z": 2 * V * 4, "corr_generic_y": 2 * V * 4, "corr_generic_x": 2 * V * 4,
+        "corr_long_y": 2 * V * 4, "corr_long_x": 2 * V * 4,
+        "argmax_z": V * 4 + P * 16,
+        "mask_ypass": P * 4 + V * 4,
+        "xpass_wmax": V * 4 + C * V * 2 + C * P * 8,
+    }
+    return table.get(kernel)
+
+
+def algorithmic_dp_ops(kernel, Z, Y, X):
+    """Separately rounded double-precision operations per launch (3 per tap pair + 1): the exact-scipy contract."""
+    V = Z * Y * X
+    if kernel in ("corr_long_y", "corr_long_x"):
+        return V * (120 * 3 + 1)
+    return None
+
+
+def cpu_baseline(sample_yx, Z, workload):
+    """Times the CPU oracle (a C/numpy port of the reference path, single thread like scipy.ndimage) on a crop."""
+    from oracle import oracle as orc
+    from tissue_image_processing_amd import synthetic
+    Ys, Xs = sample_yx
+    st = synthetic.make_stack(Z, Ys, Xs, seed=1234)
+    t0 = time.perf_counter()
+    proj, zmap = orc.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    if workload != "projection":
+        lab = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
+        orc.frame_cellinfo(lab)
+    dt = time.perf_counter() - t0
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
+    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from tissue_image_processing_amd import _lib, synthetic
+    from tissue_image_processing_amd.pipeline import FramePipeline
+    _lib.init(local_rank)
+    lib = _lib.lib()
+    Y, X, Z = args.size
+    C = 2
+    workload = args.workload
+    has_seg = hasattr(lib, "tip_watershed_segmentation_f64_dev")
+    if workload == "auto":
+        workload = "classical" if has_seg else "projection"
+
+    # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
+    st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
+    pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False)
+    frames = [pipe.upload_stack(st), pipe.upload_stack(np.ascontiguousarray(st[:, :, :, ::-1]))]
+    del st
+
+    def step(i):
+        pipe.project(frames[i % 2])
+        if workload == "classical":
+            pipe.segment(0)
+            pipe.cell_tables()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        pipe.sync()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        rep = _lib.prof_report()
+        total_kernel_ms = sum(v[1] for v in rep.values())
+        dom = max(rep.items(), key=lambda kv: kv[1][1])
+        name, (cnt, ms) = dom
+        avg_s = ms / cnt / 1e3
+        ab = algorithmic_bytes(name, C, Z, Y, X)
+        roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "avg_launch_ms": ms / cnt, "launches": cnt,
+                "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
+        if ab:
+            roof["achieved"] = ab / avg_s / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["algorithmic_bytes"] = ab
+        ops = algorithmic_dp_ops(name, Z, Y, X)
+        if ops:
+            # honest second bound: this kernel is FP64-VALU bound by construction (exact scipy arithmetic)
+            tf = ops / avg_s / 1e12
+            roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
+                                 "frac": tf / (FP64_VALU_PEAK_TF / 2),
+                                 "note": "separately rounded mul/add: one lane-op per instruction, peak = FMA peak / 2"}
+        kernels = {k: {"n": v[0], "ms_total": round(v[1], 4)} for k, v in rep.items()}
+        out = {
+            "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, {
+                "projection": "surface_projection",
+                "classical": "surface_projection+watershed_segmentation+cell_tables"}[workload]),
+                "frames_per_step": world, "parallelism": "frame-sharded dp%d, no data-path collective" % world},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            Ys, Xs = min(Y, 512), min(X, 512)
+            dt = cpu_baseline((Ys, Xs), Z, workload)
+            scale = (Y * X) / float(Ys * Xs)
+            out["cpu_baseline"] = {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle, %.1f s, "
+                                             "scaled by pixel count" % (Ys, Xs, Z, scale, dt)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Device-resident per-frame pipeline (projection -> segmentation -> cell tables) and frame sharding.
+
+One process per GPU; frames are independent units (sp.py:211 loop, gui.py:1840 loop), so a movie shards
+`frame t -> rank t % world` with no data-path collective; only the per-frame cell tables are gathered to rank 0
+for track stitching (tissue_info.track_cells_iterator, ti.py:2037-2113), which is sequential over frames.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .basic_image_manipulations import gaussian_taps
+
+
+class FramePipeline:
+    """Keeps one frame's buffers resident in HBM between stages (inputs uploaded once, outputs fetched on demand)."""
+
+    def __init__(self, C, Z, Y, X, reference_channel=0, airyscan=False, atoh_shift=0,
+                 imgthresh=0.03, stdeviation=3.0, blocksize=3, device=None):
+        if device is not None:
+            _lib.init(device)
+        self.lib = _lib.lib()
+        self.C, self.Z, self.Y, self.X = C, Z, Y, X
+        self.ref, self.airy, self.atoh = reference_channel, airyscan, atoh_shift
+        self.imgthresh, self.std, self.block = imgthresh, stdeviation, blocksize
+        self.t05, self.t1, self.t2, self.t30 = (gaussian_taps(s) for s in (0.5, 1.0, 2.0, 30.0))
+        self.tseg = gaussian_taps(stdeviation)
+        P = Y * X
+        self.d_proj = _lib.DeviceBuffer(C * P * 8)
+        self.d_zmap = _lib.DeviceBuffer(P * 8)
+        self.d_labels = _lib.DeviceBuffer(P * 4)
+        self.flags = ctypes.c_int32(0)
+        self.n_labels = 0
+
+    def upload_stack(self, stack_u16):
+        stack_u16 = np.ascontiguousarray(stack_u16, dtype=np.uint16)
+        assert stack_u16.shape == (self.C, self.Z, self.Y, self.X)
+        buf = _lib.DeviceBuffer(stack_u16.nbytes)
+        buf.upload(stack_u16)
+        return buf
+
+    def project(self, d_stack):
+        """P0-P9 (sp.py:17-85) on a resident uint16 stack; asynchronous."""
+        _lib.check(self.lib.tip_project_u16_dev(
+            _lib.dptr(d_stack.ptr), self.C, self.Z, self.Y, self.X, 0, self.Z, 0, self.ref,
+            1 if self.airy else 0, self.atoh, _lib.ptr(self.t05), _lib.ptr(self.t1), _lib.ptr(self.t2),
+            _lib.ptr(self.t30), _lib.dptr(self.d_proj.ptr), _lib.dptr(self.d_zmap.ptr)))
+
+    def segment(self, channel=0):
+        """W1-W3 (bim.py:446-476) on the resident projection of `channel`."""
+        P = self.Y * self.X
+        img = self.d_proj.ptr + channel * P * 8
+        _lib.check(self.lib.tip_watershed_segmentation_f64_dev(
+            _lib.dptr(img), _lib.dptr(self.d_labels.ptr), self.Y, self.X, ctypes.c_double(self.imgthresh),
+            _lib.ptr(self.tseg), self.tseg.size, self.block, ctypes.byref(self.flags)))
+
+    def sync(self):
+        _lib.check(self.lib.tip_sync())
+
+    def fetch_projection(self):
+        return (self.d_proj.download((self.C, self.Y, self.X), np.float64),
+                self.d_zmap.download((self.Y, self.X), np.int64))
+
+    def fetch_labels(self):
+        return self.d_labels.download((self.Y, self.X), np.int32)
+
+
+def frames_for_rank(n_frames, rank, world):
+    """frame t -> rank t % world."""
+    return list(range(rank, n_frames, world))
