@@ -1,0 +1,209 @@
+"""GPU parity: rank filters, CCL, watershed, cell tables, tracking (through the C-ABI) vs goldens and the oracle."""
+import numpy as np
+import pytest
+
+from gpu_util import taps_patch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def env(monkeypatch, golden_taps, oracle_with_golden_taps):
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    from tissue_image_processing_amd import _segmentation as seg
+    from tissue_image_processing_amd import tissue_info as ti
+    taps_patch(monkeypatch, golden_taps)
+    return bim, seg, ti, oracle_with_golden_taps
+
+
+def label_iou(test, ref):
+    ious = []
+    for l in np.unique(ref):
+        if l == 0:
+            continue
+        m = ref == l
+        cand = np.bincount(test[m])
+        cand[0] = 0
+        if cand.sum() == 0:
+            ious.append(0.0)
+            continue
+        k = cand.argmax()
+        ious.append((m & (test == k)).sum() / float((m | (test == k)).sum()))
+    return float(np.mean(ious))
+
+
+def test_rank_filters_golden(env, golden):
+    _, seg, _, _ = env
+    g = golden("rank_filters")
+    lab, img = g["lab"], g["img"]
+    np.testing.assert_array_equal(seg.maximum_filter(lab, (5, 5), mode="constant"), g["max5_const"])
+    np.testing.assert_array_equal(seg.maximum_filter(lab, (3, 3), mode="constant"), g["max3_const"])
+    np.testing.assert_array_equal(seg.maximum_filter(lab, footprint=True, mode="constant"), g["max_cross_const"])
+    np.testing.assert_array_equal(seg.minimum_filter(lab, footprint=True, mode="constant"), g["min_cross_const"])
+    np.testing.assert_array_equal(seg.maximum_filter(img, 7), g["max7_reflect_f64"])
+    np.testing.assert_array_equal(seg.maximum_filter(img, 4), g["max4_reflect_f64"])
+    b = g["binimg"]
+    np.testing.assert_array_equal(seg.maximum_filter(b, 5), g["dil5"])
+    np.testing.assert_array_equal(seg.minimum_filter(b, 5), g["ero5"])
+    np.testing.assert_array_equal(seg.minimum_filter(b, 7), g["ero7"])
+    np.testing.assert_array_equal(seg.minimum_filter(img, 7), g["ero7_gray"])
+
+
+def test_label_golden(env, golden):
+    _, seg, _, _ = env
+    g = golden("label")
+    out, n = seg.label(g["bin"], background=0, return_num=True, connectivity=1)
+    np.testing.assert_array_equal(out, g["label_bg0"])
+    assert n == g["label_bg0"].max()
+    np.testing.assert_array_equal(seg.label(g["img255"], background=255, connectivity=1), g["label_bg255"])
+    np.testing.assert_array_equal(seg.label(g["multi"], background=0, connectivity=1), g["label_multi_bg0"])
+    np.testing.assert_array_equal(seg.label(g["snake"], background=0, connectivity=1), g["label_snake"])
+
+
+def test_label_large_vs_oracle(env):
+    _, seg, _, orc = env
+    rng = np.random.default_rng(3)
+    a = (rng.random((700, 900)) > 0.42).astype(np.int32)
+    a[100:400, 200:600] = 1   # one huge component
+    a[::7, :] = 0
+    ref, n_ref = orc.label4(a, 0)
+    out, n = seg.label(a, background=0, return_num=True, connectivity=1)
+    assert n == n_ref
+    np.testing.assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("case", ["ii", "iii", "iv"])
+def test_watershed_float_golden_bit_exact(env, golden, case):
+    """Distinct-valued float landscapes: labels identical to skimage's serial flood."""
+    _, seg, _, _ = env
+    g = golden("watershed")
+    out, flags = seg.watershed(g[case + "_img"], return_flags=True)
+    assert out.dtype == np.int32
+    mism = int((out != g[case + "_labels"]).sum())
+    assert mism == 0, "label mismatches: %d (flags %d)" % (mism, flags)
+    assert not (flags & 2)
+
+
+def test_watershed_misc_golden(env, golden):
+    _, seg, _, _ = env
+    g = golden("watershed")
+    np.testing.assert_array_equal(seg.watershed(np.full((12, 14), 3.5)), g["vii_const_labels"])
+    np.testing.assert_array_equal(seg.watershed(g["vii_bowl"]), g["vii_bowl_labels"])
+
+
+def test_watershed_segmentation_golden_bit_exact(env, golden):
+    bim, _, _, _ = env
+    g = golden("watershed")
+    for key, args, lk in [("i_img", (0.03, 3, 3), "i_labels"), ("i2_img", (0.03, 3, 3), "i2_labels"),
+                          ("i2_img", (0.2, 2, 4), "i3_labels")]:
+        out = bim.watershed_segmentation(g[key], *args)
+        assert out.dtype == np.int32
+        mism = int((out != g[lk]).sum())
+        assert mism == 0, "%s: %d label mismatches" % (lk, mism)
+
+
+def test_watershed_binary_iou(env, golden):
+    """Two-valued boundary image (pl.py:194): the serial result depends on heap sift order of equal keys; the
+    BFS flood uses a documented tie-break.  Same markers, same number of lines to within a few pixels, IoU reported."""
+    _, seg, _, _ = env
+    g = golden("watershed")
+    out, flags = seg.watershed(g["vi_boundary"], return_flags=True)
+    assert flags & 2
+    ref = g["vi_labels"]
+    assert out.max() == ref.max()
+    iou = label_iou(out, ref)
+    frac = float((out != ref).mean())
+    print("binary watershed: IoU %.4f, mismatching pixels %.2f%%, lines %d vs %d" % (iou, 100 * frac, (out == 0).sum(), (ref == 0).sum()))
+    assert iou > 0.9
+    assert frac < 0.03
+    # every labelled pixel keeps the label of a marker component: markers (zeros of the image) are identical
+    zeros = g["vi_boundary"] == 0
+    np.testing.assert_array_equal(out[zeros], ref[zeros])
+
+
+def test_watershed_vs_oracle_synthetic_frame(env):
+    """Full classical segmentation of a synthetic frame, labels bit-identical to the oracle."""
+    bim, _, _, orc = env
+    from tissue_image_processing_amd import synthetic
+    from tissue_image_processing_amd import surface_projection as sp
+    st = synthetic.make_stack(10, 384, 512, seed=33)
+    proj, _ = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    zo = proj[0].T.copy()   # gui.py:1841-1844 passes the transposed ZO projection
+    out, flags = __import__("tissue_image_processing_amd._segmentation", fromlist=["x"]).watershed_segmentation(
+        zo, 0.03, 3, 3, return_flags=True)
+    ref = orc.watershed_segmentation(zo, 0.03, 3, 3)
+    mism = int((out != ref).sum())
+    print("synthetic frame: %d labels, flags %d (fallback steps %d), mismatches %d" % (ref.max(), flags & 3, flags >> 2, mism))
+    assert mism == 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cellinfo_golden(env, golden, tag):
+    _, seg, ti, _ = env
+    g = golden("cellinfo")
+    lab = g[tag + "_labels"]
+    t = ti.Tissue(1)
+    t.set_labels(1, lab.copy(), reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    ci = t.get_cells_info(1)
+    np.testing.assert_array_equal(ci.area.to_numpy(), g[tag + "_area"])
+    np.testing.assert_array_equal(ci.label.to_numpy(), g[tag + "_label"])
+    np.testing.assert_allclose(ci.perimeter.to_numpy(), g[tag + "_perimeter"], rtol=1e-13)
+    np.testing.assert_array_equal(ci.cx.to_numpy(), g[tag + "_cx"])
+    np.testing.assert_array_equal(ci.cy.to_numpy(), g[tag + "_cy"])
+    for col in ["bounding_box_min_row", "bounding_box_min_col", "bounding_box_max_row", "bounding_box_max_col",
+                "valid", "n_neighbors"]:
+        np.testing.assert_array_equal(ci[col].to_numpy(), g[tag + "_" + col], err_msg=col)
+    nb = g[tag + "_neighbors"]
+    for i, s in enumerate(ci.neighbors):
+        assert sorted(int(v) for v in s) == [int(v) for v in nb[i] if v > 0], i
+    np.testing.assert_array_equal(t.calc_neighbors_contact_matrix(1), g[tag + "_contact"])
+
+
+def test_update_labels_golden(env, golden):
+    _, _, ti, _ = env
+    g = golden("cellinfo")
+    t = ti.Tissue(1)
+    t.set_labels(1, g["u_in"].copy(), reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    t.update_labels(1)
+    np.testing.assert_array_equal(t.get_labels(1), g["u_out"])
+
+
+def test_celltypes_pins(env, golden):
+    _, seg, ti, _ = env
+    g = golden("celltypes")
+    lab, inten = g["labels"], g["intensity"]
+    rp = seg.regionprops_arrays(lab, intensity=inten)
+    np.testing.assert_allclose(rp["intensity_mean"], g["mean"], rtol=1e-12)
+    np.testing.assert_array_equal(ti.find_local_maxima(inten, window_size=7), g["local_maxima"])
+    t = ti.Tissue(1)
+    t.set_labels(1, lab.copy(), reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    t.calc_cell_types(inten, 1, "HC", threshold=0.5, percentage_above_threshold=90)
+    ci = t.get_cells_info(1)
+    # positives are exactly the cells whose 10th percentile exceeds 0.5 * p99 (ti.py:2369-2373)
+    expect = g["p10"] > 0.5 * g["p99"]
+    got = np.asarray(ti.is_positive_for_type(ci.type.to_numpy(), 0))
+    np.testing.assert_array_equal(got, expect)
+    types = t.get_cell_types(1)
+    assert types.shape == lab.shape
+
+
+def test_tracking_golden(env, golden):
+    _, _, ti, _ = env
+    g = golden("tracking")
+    labs = g["labels"]
+    t = ti.Tissue(labs.shape[0])
+    for f in range(labs.shape[0]):
+        t.set_labels(f + 1, labs[f].copy(), reset_data=True)
+        t.calculate_frame_cellinfo(f + 1)
+    t.drifts[1] = (0.5, -0.3)
+    t.drifts[2] = (0.5, -0.3)
+    frames = list(t.track_cells_iterator(1, labs.shape[0]))
+    assert frames == [2, 3]
+    for f in range(labs.shape[0]):
+        np.testing.assert_array_equal(t.get_cells_info(f + 1).label.to_numpy(), g["ids_%d" % f])
+    tl = t.get_trackking_labels(3)
+    lut = np.insert(g["ids_2"], 0, 0)
+    np.testing.assert_array_equal(tl, lut[labs[2]])

@@ -1,0 +1,645 @@
+// tip_watershed.hip -- skimage.segmentation.watershed(image, markers=None, connectivity=1, watershed_line=True)
+// (reference call sites bim.py:475 and pl.py:194) as a data-parallel flood.
+//
+// The serial algorithm (skimage/segmentation/_watershed_cy.pyx, restated in oracle/tip_oracle.c) pops pixels from
+// a (value, age) heap.  What decides a pixel's fate is only WHICH OF ITS NEIGHBOURS WERE LABELLED BEFORE IT POPS:
+//   * a pixel pops at time T = (value, index) -- or, if every lower neighbour is a watershed line, right after the
+//     first neighbour that gets labelled later ("pulled", it then inherits that neighbour's pop time and label);
+//   * when it pops, it becomes a line if the neighbours labelled before it carry >= 2 different labels, else it
+//     takes their label.
+// Mode A ("rounds") evaluates exactly that rule for every undecided pixel in parallel and only commits a pixel when
+// the states it read certify the outcome (a not-yet-decided neighbour that could still pop earlier makes the pixel
+// wait; a bounded flood of the "pocket" of earlier-keyed undecided pixels proves that nothing can reach it first).
+// Decisions are monotone, so stale reads are merely conservative, and tiles iterate to a local fixed point in LDS.
+// If a round makes no progress the pixel with the globally smallest pop time is committed (always safe), which
+// keeps the result identical to the serial flood for any image whose non-marker pixels carry distinct values.
+// Equal values between non-marker neighbours are ordered by raster index instead of the serial heap's push age:
+// `flags` bit0 reports that such ties were met.
+// Mode B handles two-valued images (pl.py:194 floods a {0,255} boundary image): generation-synchronous BFS from the
+// low-valued components, ties inside a generation broken by raster index.  The serial result there depends on the
+// sift order of millions of equal-keyed heap entries; mode B is the same flood with a different, documented,
+// tie-break (label IoU vs the reference is reported by the tests).
+#include "tip_internal.h"
+#include "tip_uf.h"
+
+namespace tip {
+
+int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
+
+// ---- helpers ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long enc_f64(double d)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long e)
+{
+    unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffULL) : ~e;
+    return __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ unsigned long long pack_st(int lab, int tref)
+{
+    return ((unsigned long long)(unsigned)tref << 32) | (unsigned)lab;
+}
+__device__ __forceinline__ int st_lab(unsigned long long s) { return (int)(unsigned)(s & 0xffffffffULL); }
+__device__ __forceinline__ int st_tref(unsigned long long s) { return (int)(unsigned)(s >> 32); }
+
+struct WsInfo {           // device-resident scalars
+    unsigned long long emin, emax;   // encoded min / max of the image
+    unsigned long long n_other;      // pixels that are neither min nor max
+    int ties;                        // equal-valued non-marker neighbours exist
+    int n_markers;
+    int changed, undecided;          // per-iteration counters (mode A) / frontier, pending (mode B)
+    unsigned long long fb_v, fb_k;   // fallback reduction
+};
+
+__global__ void __launch_bounds__(256) k_ws_minmax(const double *__restrict__ v, long n, WsInfo *info)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long lo = ~0ULL, hi = 0ULL;
+    if (i < n) { lo = hi = enc_f64(v[i]); }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&info->emin, lo); atomicMax(&info->emax, hi); }
+}
+
+__global__ void __launch_bounds__(256) k_ws_count_other(const double *__restrict__ v, long n, WsInfo *info)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < n) { const unsigned long long e = enc_f64(v[i]); c = (e != info->emin && e != info->emax); }
+    const unsigned long long m = __ballot(c);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&info->n_other, (unsigned long long)__popcll(m));
+}
+
+// ---- markers: label(local_minima(image)) ---------------------------------------------------------------------------
+struct SameF64 {
+    const double *v;
+    __device__ __forceinline__ bool valid(int) const { return true; }
+    __device__ __forceinline__ bool same(int i, int j) const { return v[i] == v[j]; }
+};
+
+// flag[root] |= 1 when the plateau has a strictly lower 4-neighbour, or equals the global maximum and touches the
+// image border (skimage pads with the value no candidate can beat and rejects plateaus that equal it, extrema.py)
+__global__ void __launch_bounds__(256) k_ws_lower_flags(const double *__restrict__ v, const int *__restrict__ parent,
+                                                        int *__restrict__ flag, int Y, int X, const WsInfo *info)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const int i = y * X + x;
+    const double h = v[i];
+    bool bad = false;
+    if (y > 0 && v[i - X] < h) bad = true;
+    if (x > 0 && v[i - 1] < h) bad = true;
+    if (x < X - 1 && v[i + 1] < h) bad = true;
+    if (y < Y - 1 && v[i + X] < h) bad = true;
+    if ((y == 0 || x == 0 || y == Y - 1 || x == X - 1) && enc_f64(h) == info->emax) bad = true;
+    if (bad) atomicOr(&flag[parent[i]], 1);
+}
+
+__global__ void __launch_bounds__(256) k_ws_min_roots(const int *__restrict__ parent, const int *__restrict__ flag,
+                                                      int *__restrict__ isroot, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) isroot[i] = (parent[i] == (int)i && flag[i] == 0) ? 1 : 0;
+}
+
+// st[i] = (marker label, tref = i) or (0, 0); also detects value ties between non-marker neighbours
+__global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict__ v, const int *__restrict__ parent,
+                                                       const int *__restrict__ flag, const int *__restrict__ rank,
+                                                       unsigned long long *__restrict__ st, int Y, int X, WsInfo *info)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const int i = y * X + x;
+    const int r = parent[i];
+    const bool is_min = flag[r] == 0;
+    st[i] = is_min ? pack_st(rank[r] + 1, i) : 0ULL;
+    if (!is_min) {
+        const double h = v[i];
+        bool tie = false;
+        if (x > 0 && v[i - 1] == h) tie = true;
+        if (y > 0 && v[i - X] == h) tie = true;
+        if (tie) info->ties = 1;
+    }
+}
+
+// ---- mode A: tile-local rounds ------------------------------------------------------------------------------------------
+constexpr int WT = 32;           // tile interior
+constexpr int WH = 5;            // halo (pocket flood needs p +- 5)
+constexpr int WL = WT + 2 * WH;  // 42
+constexpr int LINE_LAB = -1;
+
+struct T2 { double v; int i; };
+__device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
+
+struct TileView {
+    const double *sv, *stv;
+    const int *slab, *sti;
+    int gy0, gx0, X;  // global coords of local (0,0)
+    __device__ __forceinline__ int gidx(int c) const { return (gy0 + c / WL) * X + gx0 + c % WL; }
+    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], gidx(c)}; }
+    __device__ __forceinline__ T2 T(int c) const { return T2{stv[c], sti[c]}; }
+};
+
+// Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
+// key < t around q inside a 7x7 window (bit masks, no scratch); it is closed iff nothing labelled before t touches it.
+__device__ bool ws_cert(const TileView &tv, int q, int asker, const T2 &t)
+{
+    const int qy = q / WL, qx = q % WL;
+    auto bit = [&](int c) -> int {
+        const int dy = c / WL - qy + 3, dx = c % WL - qx + 3;
+        return (dy < 0 || dy > 6 || dx < 0 || dx > 6) ? -1 : dy * 7 + dx;
+    };
+    unsigned long long seen = 1ULL << 24, todo = 1ULL << 24;  // (3,3) = q
+    {
+        const int b = bit(asker);
+        if (b >= 0) seen |= 1ULL << b;
+    }
+    int pops = 0;
+    while (todo) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (++pops > 32) return false;
+        const int c = (qy + b / 7 - 3) * WL + (qx + b % 7 - 3);
+        const int nb[4] = {c - WL, c - 1, c + 1, c + WL};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = nb[k];
+            if (m == asker) continue;
+            const int l = tv.slab[m];
+            if (l == LINE_LAB) continue;
+            if (l > 0) {
+                if (t_lt(tv.T(m), t)) return false;
+            } else if (t_lt(tv.key(m), t)) {
+                const int mb = bit(m);
+                if (mb < 0) return false;  // pocket leaves the window: cannot certify
+                if (!((seen >> mb) & 1ULL)) { seen |= 1ULL << mb; todo |= 1ULL << mb; }
+            }
+        }
+    }
+    return true;
+}
+
+struct Decision { int lab; double tv; int ti; };  // lab == 0: no decision
+
+__device__ Decision ws_decide(const TileView &tv, int c, bool force)
+{
+    Decision d{0, 0.0, 0};
+    const int nb[4] = {c - WL, c - 1, c + 1, c + WL};
+    bool haslab = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) haslab |= tv.slab[nb[k]] > 0;
+    if (!haslab) return d;
+    const T2 kp = tv.key(c);
+    int s_lab = 0;
+    bool conflict = false, has_pull = false;
+    T2 pull_t{0.0, 0};
+    int pull_lab = 0;
+    unsigned und_mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = nb[k];
+        const int l = tv.slab[q];
+        if (l == LINE_LAB) continue;
+        if (l > 0) {
+            const T2 tq = tv.T(q);
+            if (t_lt(tq, kp)) {
+                if (s_lab == 0) s_lab = l;
+                else if (s_lab != l) conflict = true;
+            } else if (!has_pull || t_lt(tq, pull_t)) {
+                has_pull = true; pull_t = tq; pull_lab = l;
+            }
+        } else {
+            und_mask |= 1u << k;
+            if (!force && t_lt(tv.key(q), kp) && !ws_cert(tv, q, c, kp)) return d;
+        }
+    }
+    if (s_lab != 0) {
+        d.lab = conflict ? LINE_LAB : s_lab;
+        d.tv = kp.v; d.ti = kp.i;
+        return d;
+    }
+    if (!has_pull) return d;
+    if (!force) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((und_mask >> k) & 1u)) continue;
+            const int q = nb[k];
+            if (t_lt(pull_t, tv.key(q))) continue;
+            if (!ws_cert(tv, q, c, pull_t)) return d;
+        }
+    }
+    d.lab = pull_lab; d.tv = pull_t.v; d.ti = pull_t.i;
+    return d;
+}
+
+__global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
+                                                  int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
+                                                  unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
+                                                  int first, int max_rounds, WsInfo *info)
+{
+    __shared__ double sv[WL * WL];
+    __shared__ double stv[WL * WL];
+    __shared__ int slab[WL * WL];
+    __shared__ int sti[WL * WL];
+    __shared__ int s_any;
+    const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
+    if (!first) {
+        if (tile_und[tile] == 0) return;
+        bool act = false;
+        for (int j = -1; j <= 1; ++j)
+            for (int i = -1; i <= 1; ++i) {
+                const int yy = ty + j, xx = tx + i;
+                if (yy >= 0 && yy < tilesY && xx >= 0 && xx < tilesX) act |= changed_prev[yy * tilesX + xx] != 0;
+            }
+        if (!act) return;
+    }
+    const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
+    for (int c = threadIdx.x; c < WL * WL; c += 256) {
+        const int gy = gy0 + c / WL, gx = gx0 + c % WL;
+        if (gy < 0 || gy >= Y || gx < 0 || gx >= X) {
+            slab[c] = LINE_LAB; sv[c] = 0.0; stv[c] = 0.0; sti[c] = 0;
+        } else {
+            const int gi = gy * X + gx;
+            const unsigned long long s = st[gi];
+            const int l = st_lab(s), tr = st_tref(s);
+            const double val = v[gi];
+            sv[c] = val; slab[c] = l; sti[c] = tr;
+            stv[c] = l > 0 ? (tr == gi ? val : v[tr]) : 0.0;
+        }
+    }
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    TileView tv{sv, stv, slab, sti, gy0, gx0, X};
+    int cells[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = threadIdx.x + k * 256;
+        cells[k] = (p / WT + WH) * WL + (p % WT + WH);
+    }
+    int my_changes = 0;
+    for (int round = 0; round < max_rounds; ++round) {
+        Decision dec[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dec[k].lab = 0;
+            if (slab[cells[k]] == 0) {
+                dec[k] = ws_decide(tv, cells[k], false);
+                any |= dec[k].lab != 0;
+            }
+        }
+        __syncthreads();
+        if (any) s_any = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (dec[k].lab != 0) {
+                slab[cells[k]] = dec[k].lab; stv[cells[k]] = dec[k].tv; sti[cells[k]] = dec[k].ti;
+                my_changes++;
+            }
+        __syncthreads();
+        const int go = s_any;
+        __syncthreads();
+        if (!go) break;
+        if (threadIdx.x == 0) s_any = 0;
+        // (the next round's first barrier orders this reset before any new set)
+    }
+    int und = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = cells[k];
+        const int gy = gy0 + c / WL, gx = gx0 + c % WL;
+        if (gy < Y && gx < X) {
+            const int l = slab[c];
+            if (l == 0) und++;
+            else {
+                const int gi = gy * X + gx;
+                if (st_lab(st[gi]) == 0) st[gi] = pack_st(l, sti[c]);
+            }
+        }
+    }
+    const int tot_changes = __syncthreads_count(my_changes > 0);
+    __shared__ int s_und;
+    if (threadIdx.x == 0) s_und = 0;
+    __syncthreads();
+    if (und) atomicAdd(&s_und, und);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_und[tile] = s_und;
+        changed_cur[tile] = tot_changes > 0;
+        if (tot_changes > 0) atomicAdd(&info->changed, tot_changes);
+        if (s_und) atomicAdd(&info->undecided, s_und);
+    }
+}
+
+// fallback: the undecided pixel with the globally smallest pop time is always safe to commit
+__device__ __forceinline__ bool ws_heap_key(const double *v, const unsigned long long *st, int Y, int X, int i, T2 &pt)
+{
+    const int y = i / X, x = i % X;
+    const T2 kp{v[i], i};
+    bool has = false;
+    T2 best{0.0, 0};
+    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
+    for (int k = 0; k < 4; ++k) {
+        if (nb[k] < 0) continue;
+        const unsigned long long s = st[nb[k]];
+        if (st_lab(s) > 0) {
+            const int tr = st_tref(s);
+            const T2 tq{v[tr], tr};
+            if (!has || t_lt(tq, best)) { best = tq; has = true; }
+        }
+    }
+    if (!has) return false;
+    pt = t_lt(kp, best) ? best : kp;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_ws_fb_min1(const double *__restrict__ v, const unsigned long long *__restrict__ st, int Y,
+                                                    int X, WsInfo *info)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Y * X || st_lab(st[i]) != 0) return;
+    T2 pt;
+    if (ws_heap_key(v, st, Y, X, (int)i, pt)) atomicMin(&info->fb_v, enc_f64(pt.v));
+}
+
+__global__ void __launch_bounds__(256) k_ws_fb_min2(const double *__restrict__ v, const unsigned long long *__restrict__ st, int Y,
+                                                    int X, WsInfo *info)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Y * X || st_lab(st[i]) != 0) return;
+    T2 pt;
+    if (ws_heap_key(v, st, Y, X, (int)i, pt) && enc_f64(pt.v) == info->fb_v)
+        atomicMin(&info->fb_k, ((unsigned long long)(unsigned)pt.i << 32) | (unsigned)i);
+}
+
+__global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X, WsInfo *info)
+{
+    if (info->fb_k == ~0ULL) return;
+    const int i = (int)(unsigned)(info->fb_k & 0xffffffffULL);
+    const int y = i / X, x = i % X;
+    const T2 kp{v[i], i};
+    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
+    int s_lab = 0, pull_lab = 0, pull_tr = 0;
+    bool conflict = false, has_pull = false;
+    T2 pull_t{0.0, 0};
+    for (int k = 0; k < 4; ++k) {
+        if (nb[k] < 0) continue;
+        const unsigned long long s = st[nb[k]];
+        const int l = st_lab(s);
+        if (l <= 0) continue;
+        const int tr = st_tref(s);
+        const T2 tq{v[tr], tr};
+        if (t_lt(tq, kp)) {
+            if (s_lab == 0) s_lab = l;
+            else if (s_lab != l) conflict = true;
+        } else if (!has_pull || t_lt(tq, pull_t)) {
+            has_pull = true; pull_t = tq; pull_lab = l; pull_tr = tr;
+        }
+    }
+    if (s_lab != 0) st[i] = pack_st(conflict ? LINE_LAB : s_lab, i);
+    else if (has_pull) st[i] = pack_st(pull_lab, pull_tr);
+    info->changed = 1;
+}
+
+// ---- mode B: generation-synchronous BFS on a two-valued image --------------------------------------------------------
+// st: low = label / 0 / LINE, high = generation (0 for markers).  tent: tentative label of this generation's frontier
+// (0 none, >0 label), fate: 0 pending, 1 labelled, 2 line.
+__global__ void __launch_bounds__(256) k_bfs_prepare(unsigned long long *__restrict__ st, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && st_lab(st[i]) > 0) st[i] = pack_st(st_lab(st[i]), 0);  // markers are generation 0
+}
+
+__global__ void __launch_bounds__(256) k_bfs_tent(unsigned long long *__restrict__ st, int *__restrict__ tent,
+                                                  unsigned char *__restrict__ fate, int Y, int X, int gen, WsInfo *info)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const int i = y * X + x;
+    tent[i] = 0;
+    if (st_lab(st[i]) != 0) return;
+    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
+    int s = 0;
+    bool conflict = false;
+    for (int k = 0; k < 4; ++k) {
+        if (nb[k] < 0) continue;
+        const unsigned long long q = st[nb[k]];
+        const int l = st_lab(q);
+        if (l > 0 && st_tref(q) < gen) {
+            if (s == 0) s = l;
+            else if (s != l) conflict = true;
+        }
+    }
+    if (s == 0) return;
+    if (conflict) { tent[i] = -1; fate[i] = 2; }
+    else { tent[i] = s; fate[i] = 0; atomicAdd(&info->undecided, 1); }
+    atomicAdd(&info->changed, 1);
+}
+
+__global__ void __launch_bounds__(256) k_bfs_resolve(const int *__restrict__ tent, unsigned char *__restrict__ fate, int Y, int X,
+                                                     WsInfo *info)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const int i = y * X + x;
+    const int t = tent[i];
+    if (t <= 0 || fate[i] != 0) return;
+    bool pending = false, line = false;
+    const int nb[2] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1};  // earlier raster index pops first
+    for (int k = 0; k < 2; ++k) {
+        if (nb[k] < 0) continue;
+        const int tq = tent[nb[k]];
+        if (tq > 0 && tq != t) {
+            const unsigned char f = fate[nb[k]];
+            if (f == 0) pending = true;
+            else if (f == 1) line = true;
+        }
+    }
+    if (line) { fate[i] = 2; atomicAdd(&info->changed, 1); }
+    else if (!pending) { fate[i] = 1; atomicAdd(&info->changed, 1); }
+    else atomicAdd(&info->undecided, 1);
+}
+
+__global__ void __launch_bounds__(256) k_bfs_commit(unsigned long long *__restrict__ st, const int *__restrict__ tent,
+                                                    const unsigned char *__restrict__ fate, long n, int gen)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tent[i];
+    if (t == 0) return;
+    st[i] = (t > 0 && fate[i] == 1) ? pack_st(t, gen) : pack_st(LINE_LAB, gen);
+}
+
+__global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__restrict__ st, int32_t *__restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = st_lab(st[i]);
+    out[i] = l > 0 ? l : 0;
+}
+
+__global__ void k_ws_info_init(WsInfo *info)
+{
+    info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
+    info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+}
+__global__ void k_ws_iter_reset(WsInfo *info) { info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL; }
+
+int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int32_t *flags_host)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!img || !labels) return fail(TIP_ERR_ARG, "watershed: null pointer");
+    if (!wsl) return fail(TIP_ERR_UNSUPPORTED, "watershed: only watershed_line=True (the reference's call sites)");
+    if (Y < 1 || X < 1 || Y > 65535 || (long)Y * X > 2147483647L) return fail(TIP_ERR_ARG, "watershed: bad shape %dx%d", Y, X);
+    const long n = (long)Y * X;
+    WsGuard ws;
+    WsInfo *info = ws.get<WsInfo>(1);
+    int *parent = ws.get<int>(n), *flag = ws.get<int>(n), *isroot = ws.get<int>(n), *rank = ws.get<int>(n);
+    unsigned long long *st = ws.get<unsigned long long>(n);
+    if (!info || !parent || !flag || !isroot || !rank || !st) return TIP_ERR_NOMEM;
+    hipStream_t s = c.stream;
+    TIP_LAUNCH("ws_info_init", k_ws_info_init, dim3(1), dim3(1), 0, info);
+    TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(cdiv(n, 256)), dim3(256), 0, img, n, info);
+    TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(cdiv(n, 256)), dim3(256), 0, img, n, info);
+    // markers
+    SameF64 same{img};
+    int rc = uf_components(same, parent, Y, X);
+    if (rc) return rc;
+    TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));
+    TIP_LAUNCH("ws_lower_flags", k_ws_lower_flags, dim3(cdiv(X, 256), Y), dim3(256), 0, img, (const int *)parent, flag, Y, X,
+               (const WsInfo *)info);
+    TIP_LAUNCH("ws_min_roots", k_ws_min_roots, dim3(cdiv(n, 256)), dim3(256), 0, (const int *)parent, (const int *)flag, isroot, n);
+    if ((rc = exclusive_scan_i32(isroot, rank, n, &info->n_markers))) return rc;
+    TIP_LAUNCH("ws_init_state", k_ws_init_state, dim3(cdiv(X, 256), Y), dim3(256), 0, img, (const int *)parent, (const int *)flag,
+               (const int *)rank, st, Y, X, info);
+    WsInfo h;
+    TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+    TIP_HIP(hipStreamSynchronize(s));
+    int flags = h.ties ? 1 : 0;
+    const bool two_valued = h.n_other == 0 && h.emin != h.emax;
+    if (h.n_markers > 0 && two_valued) {
+        flags |= 2;  // mode B
+        int *tent = parent;                       // reuse
+        unsigned char *fate = (unsigned char *)flag;
+        TIP_LAUNCH("bfs_prepare", k_bfs_prepare, dim3(cdiv(n, 256)), dim3(256), 0, st, n);
+        for (int gen = 1;; ++gen) {
+            TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
+            TIP_LAUNCH("bfs_tent", k_bfs_tent, dim3(cdiv(X, 256), Y), dim3(256), 0, st, tent, fate, Y, X, gen, info);
+            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+            TIP_HIP(hipStreamSynchronize(s));
+            if (h.changed == 0) break;
+            int pending = h.undecided;
+            while (pending > 0) {
+                TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
+                TIP_LAUNCH("bfs_resolve", k_bfs_resolve, dim3(cdiv(X, 256), Y), dim3(256), 0, (const int *)tent, fate, Y, X, info);
+                TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipStreamSynchronize(s));
+                if (h.changed == 0 && h.undecided > 0) return fail(TIP_ERR_HIP, "watershed: BFS resolve made no progress");
+                pending = h.undecided;
+            }
+            TIP_LAUNCH("bfs_commit", k_bfs_commit, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)tent,
+                       (const unsigned char *)fate, n, gen);
+        }
+    } else if (h.n_markers > 0) {
+        const int tilesX = cdiv(X, WT), tilesY = cdiv(Y, WT), ntiles = tilesX * tilesY;
+        unsigned char *chg = ws.get<unsigned char>((size_t)2 * ntiles);
+        int *tile_und = ws.get<int>(ntiles);
+        if (!chg || !tile_und) return TIP_ERR_NOMEM;
+        TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
+        int iter = 0, fallbacks = 0;
+        for (;; ++iter) {
+            TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
+            unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
+            TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
+            TIP_LAUNCH("ws_tiles", k_ws_tiles, dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX, tilesY,
+                       (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+            TIP_HIP(hipStreamSynchronize(s));
+            if (h.changed > 0) continue;
+            // no tile made progress: either done, or pockets too large to certify locally -> commit the global minimum
+            long und_total = 0;
+            {
+                std::vector<int> hu(ntiles);
+                TIP_HIP(hipMemcpyAsync(hu.data(), tile_und, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipStreamSynchronize(s));
+                for (int v2 : hu) und_total += v2;
+            }
+            if (und_total == 0) break;
+            TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
+            TIP_LAUNCH("ws_fb_min1", k_ws_fb_min1, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
+            TIP_LAUNCH("ws_fb_min2", k_ws_fb_min2, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
+            TIP_LAUNCH("ws_fb_commit", k_ws_fb_commit, dim3(1), dim3(1), 0, img, st, Y, X, info);
+            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+            TIP_HIP(hipStreamSynchronize(s));
+            if (h.fb_k == ~0ULL) break;  // the remaining pixels are enclosed by lines: they stay 0, as in the serial flood
+            fallbacks++;
+            // wake every tile up again
+            TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+        }
+        flags |= (fallbacks & 0x3fff) << 2;
+    }
+    TIP_LAUNCH("ws_emit", k_ws_emit, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st, labels, n);
+    if (flags_host) *flags_host = flags;
+    return TIP_OK;
+}
+
+}  // namespace tip
+
+using namespace tip;
+
+extern "C" {
+
+int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host)
+{
+    return watershed_dev(img, labels, y, x, wsl, flags_host);
+}
+
+int tip_watershed_f64(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!img || !labels || y < 1 || x < 1) return fail(TIP_ERR_ARG, "tip_watershed_f64: bad arguments");
+    const size_t P = (size_t)y * x;
+    WsGuard ws;
+    double *di = ws.get<double>(P);
+    int32_t *dl = ws.get<int32_t>(P);
+    if (!di || !dl) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(di, img, P * 8, hipMemcpyHostToDevice, c.stream));
+    int rc = watershed_dev(di, dl, y, x, wsl, flags);
+    if (rc) return rc;
+    TIP_HIP(hipMemcpyAsync(labels, dl, P * 4, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_watershed_segmentation_f64_dev(const double *img, int32_t *labels, int y, int x, double imgthresh, const double *taps,
+                                       int ntaps, int block, int32_t *flags_host)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!img || !labels || y < 1 || x < 1) return fail(TIP_ERR_ARG, "tip_watershed_segmentation_f64_dev: bad arguments");
+    const size_t P = (size_t)y * x;
+    WsGuard ws;
+    double *a = ws.get<double>(P), *b = ws.get<double>(P);
+    if (!a || !b) return TIP_ERR_NOMEM;
+    int rc = tip_local_threshold_f64_dev(img, a, y, x, imgthresh, block);
+    if (rc) return rc;
+    const double *blurred = a;
+    if (taps && ntaps > 0) {
+        Taps t;
+        if ((rc = make_taps(t, taps, ntaps))) return rc;
+        if ((rc = correlate1d_dev(a, b, 1, 1, y, x, 1, t, 0))) return rc;
+        if ((rc = correlate1d_dev(b, a, 1, 1, y, x, 2, t, 0))) return rc;
+        blurred = a;
+    }
+    return watershed_dev(blurred, labels, y, x, 1, flags_host);
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+"""Drop-in for the array-heavy methods of the reference's tissue_info.Tissue (ti.py) on MI355X.
+
+`TissueHipMixin` carries the hot methods with the reference's signatures; mixing it in FRONT of the reference's
+own class (`class Tissue(TissueHipMixin, reference.Tissue)`) re-routes them to libtissue_hip.so while the
+reference's state / cache / persistence code (ti.py:193-353, 3462-3823) stays the caller, unchanged.
+`Tissue` below is a small self-contained in-memory host for the same methods (what the tests and bench use).
+
+    calculate_frame_cellinfo(frame_number)                 ti.py:880-909   -> tip_regionprops_i32 + tip_neighbor_pairs_i32
+    find_neighbors(frame_number, only_for_labels=None)     ti.py:1815-1842 -> tip_neighbor_pairs_i32
+    update_labels(frame)                                   ti.py:2967-2975 -> tip_update_labels_i32
+    calc_cell_types(...), update_cell_types_by_cells_info  ti.py:2338-2408 -> tip_regionprops_i32 (+ host order statistics)
+    calc_neighbors_contact_matrix(frame)                   ti.py:4073-4094 -> tip_rankfilter2d (cross footprint)
+    track_cells_iterator(...)                              ti.py:2037-2113 -> tip_rankfilter2d + host table logic
+    get_trackking_labels(frame)                            ti.py:4021-4028 -> tip_lut_gather_i32
+"""
+import ctypes
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+from . import _segmentation as seg
+from .basic_image_manipulations import blur_image
+
+CELL_INFO_SPECS = {"area": 0, "perimeter": 0, "label": 0, "cx": 0, "cy": 0, "neighbors": set(), "n_neighbors": 0,
+                   "valid": 0, "type": 0, "bounding_box_min_row": 0, "bounding_box_min_col": 0,
+                   "bounding_box_max_row": 0, "bounding_box_max_col": 0, "empty_cell": 0}
+INVALID_TYPE_INDEX = 255
+
+
+def make_df(number_of_lines, specs):
+    """ti.py:85-98."""
+    if number_of_lines > 0:
+        df = pd.DataFrame(index=np.arange(number_of_lines))
+        for name, val in specs.items():
+            df[name] = [set() for _ in range(number_of_lines)] if isinstance(val, set) else \
+                [list() for _ in range(number_of_lines)] if isinstance(val, list) else val
+    else:
+        df = pd.DataFrame(columns=specs.keys())
+    return df
+
+
+def find_local_maxima(arr, window_size=7):
+    """ti.py:141-144: blur sigma 7, maximum_filter(size=window) (default mode reflect), |blur - max| < 1e-6."""
+    blurred = blur_image(np.asarray(arr, dtype=np.float64), 7)
+    maxima = seg.maximum_filter(blurred, size=window_size)
+    return np.abs(blurred - maxima) < 1e-6
+
+
+def is_positive_for_type(type, type_index):
+    """ti.py:146-176 (scalar/array index branch; the tuple branch uses np.bool, removed from numpy)."""
+    if isinstance(type_index, tuple):
+        pos_types, neg_types = type_index
+        res = np.ones_like(np.asarray(type), dtype=bool)
+        for t in pos_types:
+            res &= np.asarray(is_positive_for_type(type, t), dtype=bool)
+        for t in neg_types:
+            res &= ~np.asarray(is_positive_for_type(type, t), dtype=bool)
+        return res
+    if type_index < 0:
+        return False
+    binary_location = (1 << type_index)
+    type = np.array(type).astype(np.uint8)
+    binary_location = np.ones_like(type).astype(np.uint8) * binary_location
+    res = np.bitwise_and(type, binary_location) == binary_location
+    if hasattr(res, "__len__"):
+        res[type == INVALID_TYPE_INDEX] = False
+    return res
+
+
+def change_type(current_type, type_index, is_positive):
+    """ti.py:179-191."""
+    binary_location = (1 << type_index)
+    res = np.array(current_type).astype(np.uint8)
+    if hasattr(res, "__len__") and res.ndim > 0:
+        res[np.asarray(current_type) == INVALID_TYPE_INDEX] = 0
+    elif res == INVALID_TYPE_INDEX:
+        res = np.array(0).astype(np.uint8)
+    binary_location = binary_location * np.ones_like(current_type).astype(np.uint8)
+    res = np.bitwise_and(res, np.bitwise_not(binary_location))
+    if is_positive:
+        res = np.bitwise_or(res, binary_location)
+    return res
+
+
+class TissueHipMixin(object):
+    """Hot methods of Tissue; expects the host class to provide get_labels / get_cells_info / set_cells_info /
+    get_cell_types / set_cell_types, max_cell_area, min_cell_area, type_names, drifts, valid_frames,
+    number_of_frames, cells_number (all present in the reference's class, ti.py:218-253)."""
+
+    # ---- C1 -------------------------------------------------------------------------------------------------
+    def calculate_frame_cellinfo(self, frame_number):
+        labels = self.get_labels(frame_number)
+        if labels is None:
+            return 0
+        number_of_cells = int(np.max(labels))
+        if number_of_cells == 0:
+            return 0
+        cells_info = make_df(number_of_cells, CELL_INFO_SPECS)
+        rp = seg.regionprops_arrays(labels, n=number_of_cells)
+        present = rp["area"] > 0
+        idx = np.nonzero(present)[0]
+        cells_info["perimeter"] = cells_info["perimeter"].astype(np.float64)
+        cells_info["cx"] = cells_info["cx"].astype(np.float64)
+        cells_info["cy"] = cells_info["cy"].astype(np.float64)
+        cells_info.loc[idx, "label"] = rp["label"][idx]
+        cells_info.loc[idx, "area"] = rp["area"][idx]
+        cells_info.loc[idx, "perimeter"] = rp["perimeter"][idx]
+        cells_info.loc[idx, "cx"] = rp["cx"][idx]
+        cells_info.loc[idx, "cy"] = rp["cy"][idx]
+        cells_info.loc[idx, "bounding_box_min_row"] = rp["bbox"][idx, 0]
+        cells_info.loc[idx, "bounding_box_min_col"] = rp["bbox"][idx, 1]
+        cells_info.loc[idx, "bounding_box_max_row"] = rp["bbox"][idx, 2]
+        cells_info.loc[idx, "bounding_box_max_col"] = rp["bbox"][idx, 3]
+        areas = cells_info.area.to_numpy()
+        mean_area = np.mean(areas)
+        max_area = self.max_cell_area * mean_area
+        min_area = self.min_cell_area * mean_area
+        cells_info.loc[:, "valid"] = np.logical_and(areas < max_area, areas > min_area).astype(int)
+        self.set_cells_info(frame_number, cells_info)
+        self.find_neighbors(frame_number, only_for_labels=cells_info.query("valid == 1").index.to_numpy() + 1)
+        return 0
+
+    # ---- C2 -------------------------------------------------------------------------------------------------
+    def find_neighbors(self, frame_number, only_for_labels=None):
+        labels = self.get_labels(frame_number)
+        if labels is None:
+            return 0
+        cells_info = self.get_cells_info(frame_number)
+        pairs = seg.neighbor_pairs(labels)
+        if only_for_labels is None:
+            working_indices = cells_info.query("empty_cell == 0").index.to_numpy()
+        else:
+            working_indices = np.array(only_for_labels) - 1
+        neighbors = cells_info["neighbors"].to_numpy()
+        n_neighbors = cells_info["n_neighbors"].to_numpy().copy()
+        by_hi = {}
+        for hi, lo in pairs:
+            by_hi.setdefault(int(hi), []).append(int(lo))
+        for cell_index in working_indices:
+            neighbors[cell_index] = set()
+        for cell_index in working_indices:
+            cell_label = int(cell_index) + 1
+            nl = by_hi.get(cell_label)
+            if nl:
+                neighbors[cell_index] = neighbors[cell_index].union(nl)
+                for nb in nl:
+                    neighbors[nb - 1].add(cell_label)
+                    n_neighbors[nb - 1] = len(neighbors[nb - 1])
+        for cell_index in working_indices:
+            n_neighbors[cell_index] = len(neighbors[cell_index])
+        cells_info["neighbors"] = list(neighbors)
+        cells_info["n_neighbors"] = n_neighbors
+        return
+
+    # ---- C3 -------------------------------------------------------------------------------------------------
+    def update_labels(self, frame):
+        labels = self.get_labels(frame)
+        lab32 = np.ascontiguousarray(labels, dtype=np.int32)
+        _lib.check(_lib.lib().tip_update_labels_i32(_lib.ptr(lab32), lab32.shape[0], lab32.shape[1]))
+        labels[...] = lab32
+        self.last_action = []
+        self._neighbors_labels = (0, 0)
+        self.last_added_line = []
+        self.update_cell_types_by_cells_info(frame)
+        return 0
+
+    # ---- C5 -------------------------------------------------------------------------------------------------
+    def calc_cell_types(self, type_marker_image, frame_number, type_name, threshold=0.1,
+                        percentage_above_threshold=90, peak_window_size=0):
+        cells_info = self.get_cells_info(frame_number)
+        labels = self.get_labels(frame_number)
+        if cells_info is None or labels is None:
+            return 0
+        new_type = type_name not in self.type_names
+        if new_type:
+            self.type_names.append(type_name)
+            type_index = len(self.type_names) - 1
+        else:
+            type_index = self.type_names.index(type_name)
+        img = np.asarray(type_marker_image, dtype=np.float64)
+        rp = seg.regionprops_arrays(labels, intensity=img)
+        present = rp["area"] > 0
+        cell_indices = np.nonzero(present)[0]
+        # per-label percentile(100 - p): order statistic of each region's pixels (host: one sort for all regions)
+        flat_l = np.asarray(labels).ravel()
+        order = np.lexsort((img.ravel(), flat_l))
+        sl, sv = flat_l[order], img.ravel()[order]
+        starts = np.searchsorted(sl, cell_indices + 1, side="left")
+        counts = rp["area"][cell_indices]
+        q = (100 - percentage_above_threshold) / 100.0
+        virt = counts * q + (1 + q * (1 - 1 - 1)) - 1
+        prev = np.clip(np.floor(virt).astype(np.int64), 0, counts - 1)
+        nxt = np.minimum(prev + 1, counts - 1)
+        gamma = virt - np.floor(virt)
+        lo, hi = sv[starts + prev], sv[starts + nxt]
+        diff = hi - lo
+        marker_intensities = np.where(gamma >= 0.5, hi - diff * (1 - gamma), lo + diff * gamma)
+        if new_type:
+            cells_info.loc[cell_indices, "mean_intensity_" + type_name] = rp["intensity_mean"][cell_indices]
+        areas = cells_info.area.to_numpy()
+        mean_area = np.mean(areas)
+        max_area = self.max_cell_area * mean_area
+        min_area = self.min_cell_area * mean_area
+        old_valid = cells_info.valid.to_numpy() == 1
+        new_valid = np.logical_and(areas < max_area, areas > min_area)
+        updated_labels = cells_info.iloc[np.logical_and(new_valid, ~old_valid)].index.to_numpy() + 1
+        self.find_neighbors(frame_number, only_for_labels=updated_labels)
+        cells_info = self.get_cells_info(frame_number)
+        cells_info.loc[:, "valid"] = new_valid.astype(int)
+        max_brightness = np.percentile(img, 99)
+        thr = threshold * max_brightness
+        pos_indices = cell_indices[marker_intensities > thr]
+        neg_indices = cell_indices[marker_intensities <= thr]
+        if peak_window_size > 0:
+            local_maxima = find_local_maxima(img, window_size=peak_window_size)
+            indices_with_local_maximum = np.unique(np.asarray(labels)[local_maxima]) - 1
+            indices_with_local_maximum = indices_with_local_maximum[indices_with_local_maximum > 0]
+            neg_indices = np.union1d(neg_indices, np.setdiff1d(pos_indices, indices_with_local_maximum))
+            pos_indices = np.intersect1d(pos_indices, indices_with_local_maximum)
+        current_type = cells_info.loc[pos_indices, "type"].to_numpy()
+        cells_info.loc[pos_indices, "type"] = change_type(current_type, type_index, is_positive=True)
+        current_type = cells_info.loc[neg_indices, "type"].to_numpy()
+        cells_info.loc[neg_indices, "type"] = change_type(current_type, type_index, is_positive=False)
+        self.update_cell_types_by_cells_info(frame_number)
+        return 0
+
+    def update_cell_types_by_cells_info(self, frame):
+        labels = self.get_labels(frame)
+        cells_info = self.get_cells_info(frame)
+        if labels is None or cells_info is None:
+            return 0
+        cell_types = self.get_cell_types(frame)
+        if cell_types is None:
+            cell_types = np.ones_like(labels) * INVALID_TYPE_INDEX
+        n = cells_info.shape[0]
+        # LUT per label: valid cells -> their type, invalid cells (by label column) -> 255, others keep old value
+        lut = np.full(n + 1, -1, np.int64)
+        valid = cells_info.valid.to_numpy() == 1
+        types = cells_info.type.to_numpy().astype(np.int64)
+        lut[1:][valid] = types[valid]
+        lab = np.asarray(labels)
+        sel = (lab > 0) & (lab <= n)
+        mapped = np.where(sel, lut[np.where(sel, lab, 0)], -1)
+        cell_types = np.where(mapped >= 0, mapped, cell_types)
+        invalid_cells_labels = cells_info.label.to_numpy()[~valid]
+        cell_types[np.isin(lab, invalid_cells_labels)] = INVALID_TYPE_INDEX
+        self.set_cell_types(frame, cell_types)
+        return 0
+
+    # ---- C6 -------------------------------------------------------------------------------------------------
+    def calc_neighbors_contact_matrix(self, frame):
+        labels = self.get_labels(frame)
+        cells_info = self.get_cells_info(frame)
+        if labels is None or cells_info is None:
+            return 0
+        lab32 = np.ascontiguousarray(labels, dtype=np.int32)
+        mx = seg.maximum_filter(lab32, footprint=True, mode="constant")
+        lc = lab32.copy()
+        lc[lc == 0] = np.max(lc) + 1
+        mn = seg.minimum_filter(lc, footprint=True, mode="constant")
+        max_index = cells_info.index.max()
+        output = np.zeros((max_index + 1, max_index + 1))
+        for index, cell in cells_info.iterrows():
+            r0 = int(max(0, cell.bounding_box_min_row - 2))
+            r1 = int(cell.bounding_box_max_row + 2)
+            c0 = int(max(0, cell.bounding_box_min_col - 2))
+            c1 = int(cell.bounding_box_max_col + 2)
+            mxr, mnr = mx[r0:r1, c0:c1], mn[r0:r1, c0:c1]
+            for nb in cell.neighbors:
+                hi, lo = max(index + 1, nb), min(index + 1, nb)
+                output[index, nb - 1] = np.sum(np.logical_and(mxr == hi, mnr == lo))
+        return output
+
+    # ---- T3 -------------------------------------------------------------------------------------------------
+    def track_cells_iterator(self, initial_frame=1, final_frame=-1, images=None, image_in_memory=False, use_piv=False):
+        if use_piv:
+            raise NotImplementedError("optical-flow (PIV) drift is out of scope (SURVEY.md 8f)")
+        if final_frame == -1:
+            final_frame = self.number_of_frames
+        cells_info = self.get_cells_info(initial_frame)
+        if cells_info is None:
+            return 0
+        unlabeled_cells = (cells_info.label.to_numpy() == 0)
+        last_used_label = cells_info.label.max()
+        cells_info.loc[unlabeled_cells, "label"] = np.arange(last_used_label + 1,
+                                                            last_used_label + np.sum(unlabeled_cells.astype(int)) + 1)
+        cx_previous_frame = np.copy(cells_info.cx.to_numpy())
+        cy_previous_frame = np.copy(cells_info.cy.to_numpy())
+        labels_previous_frame = cells_info.label.to_numpy()
+        empty_cells_previous_frame = cells_info.empty_cell.to_numpy()
+        previous_frame = initial_frame
+        self.cells_number = max(self.cells_number, cells_info.label.max())
+        use_existing_drifts = (self.drifts > 0).any()
+        update_next_drift = False
+        for frame in range(initial_frame + 1, final_frame + 1):
+            if self.valid_frames[frame - 1] == 0:
+                if not np.isnan(self.drifts[frame - 1, 0]):
+                    self.drifts[frame - 1, :] = np.nan
+                    update_next_drift = True
+                continue
+            if use_existing_drifts and not update_next_drift:
+                cx_previous_frame -= self.drifts[frame - 1, 1]
+                cy_previous_frame -= self.drifts[frame - 1, 0]
+            else:
+                shift_y, shift_x = self.update_drift(frame, previous_frame, images=images, image_in_memory=image_in_memory)
+                cx_previous_frame -= shift_x
+                cy_previous_frame -= shift_y
+            cells_info = self.get_cells_info(frame)
+            raw = self.get_labels(frame)
+            if cells_info is None or raw is None:
+                continue
+            labels = seg.maximum_filter(np.ascontiguousarray(raw, dtype=np.int32), (3, 3), mode="constant")
+            cells_info.loc[:, "label"] = 0
+            indices_in_current_frame = -1 * np.ones(cy_previous_frame.shape)
+            y_locations = np.round(cy_previous_frame).astype(int)
+            x_locations = np.round(cx_previous_frame).astype(int)
+            valid_locations = np.logical_and(np.logical_and(np.logical_and(0 <= y_locations, y_locations < labels.shape[0]),
+                                             np.logical_and(0 <= x_locations, x_locations < labels.shape[1])),
+                                             empty_cells_previous_frame == 0)
+            indices_in_current_frame[valid_locations] = labels[y_locations[valid_locations], x_locations[valid_locations]] - 1
+            labels_previous_frame = labels_previous_frame[indices_in_current_frame >= 0]
+            indices_in_current_frame = indices_in_current_frame[indices_in_current_frame >= 0]
+            _, loc = np.unique(labels_previous_frame, return_index=True)
+            indices_in_current_frame = indices_in_current_frame[loc]
+            labels_previous_frame = labels_previous_frame[loc]
+            _, loc = np.unique(indices_in_current_frame, return_index=True)
+            indices_in_current_frame = indices_in_current_frame[loc]
+            labels_previous_frame = labels_previous_frame[loc]
+            cells_info.loc[indices_in_current_frame.astype("int"), "label"] = labels_previous_frame
+            unlabeled_cells = (cells_info.label.to_numpy() == 0)
+            last_used_label = cells_info.label.max()
+            cells_info.loc[unlabeled_cells, "label"] = np.arange(last_used_label + 1,
+                                                                last_used_label + np.sum(unlabeled_cells.astype(int)) + 1)
+            self.cells_number = max(self.cells_number, cells_info.label.max())
+            cx_previous_frame = np.copy(cells_info.cx.to_numpy())
+            cy_previous_frame = np.copy(cells_info.cy.to_numpy())
+            labels_previous_frame = cells_info.label.to_numpy()
+            empty_cells_previous_frame = cells_info.empty_cell.to_numpy()
+            previous_frame = frame
+            yield frame
+        return 0
+
+    def update_drift(self, frame, previous_frame, images=None, image_in_memory=False):
+        """ti.py:1982-2035 without the FFT refinement (phase_cross_correlation is SURVEY.md 8f rank 2): the stage
+        shift (zero when no stage table is loaded) is stored and returned."""
+        if images is not None:
+            raise NotImplementedError("phase-correlation drift refinement is out of scope this round (SURVEY.md 8f)")
+        shift_y, shift_x = 0, 0
+        self.drifts[frame - 1, 0] = shift_y
+        self.drifts[frame - 1, 1] = shift_x
+        return shift_y, shift_x
+
+    # ---- T4 -------------------------------------------------------------------------------------------------
+    def get_trackking_labels(self, frame):
+        labels = self.get_labels(frame)
+        cells_info = self.get_cells_info(frame)
+        if labels is None or cells_info is None:
+            return None
+        cell_ids = np.ascontiguousarray(np.insert(cells_info.label.to_numpy(), 0, 0), dtype=np.int64)
+        lab32 = np.ascontiguousarray(labels, dtype=np.int32)
+        out = np.empty(lab32.shape, np.int64)
+        _lib.check(_lib.lib().tip_lut_gather_i32(_lib.ptr(lab32), _lib.ptr(cell_ids), ctypes.c_int64(cell_ids.size),
+                                                 _lib.ptr(out), ctypes.c_int64(lab32.size)))
+        return out
+
+
+class Tissue(TissueHipMixin):
+    """Minimal in-memory host of the hot methods (per-frame labels / cell tables / type maps kept in lists).
+    The reference's own Tissue (state, caching, .seg persistence, events, statistics) is out of scope."""
+
+    def __init__(self, number_of_frames, data_path=None, channel_names=(), max_cell_area=10, min_cell_area=0.1,
+                 load_to_memory=True):
+        self.number_of_frames = number_of_frames
+        self.data_path = data_path
+        self.channel_names = list(channel_names)
+        self.max_cell_area = max_cell_area
+        self.min_cell_area = min_cell_area
+        self.type_names = []
+        self.drifts = np.zeros((number_of_frames, 2))
+        self.valid_frames = np.ones((number_of_frames,)).astype(int)
+        self.cells_number = 0
+        self._labels = [None] * number_of_frames
+        self._cells_info = [None] * number_of_frames
+        self._cell_types = [None] * number_of_frames
+        self.last_action = []
+        self._neighbors_labels = (0, 0)
+        self.last_added_line = []
+
+    def set_labels(self, frame_number, labels, reset_data=False):
+        if reset_data:
+            self._cells_info[frame_number - 1] = None
+            self._cell_types[frame_number - 1] = None
+        self._labels[frame_number - 1] = labels
+
+    def get_labels(self, frame_number):
+        return self._labels[frame_number - 1]
+
+    def set_cells_info(self, frame_number, cells_info):
+        self._cells_info[frame_number - 1] = cells_info
+
+    def get_cells_info(self, frame_number, type_name=""):
+        return self._cells_info[frame_number - 1]
+
+    def set_cell_types(self, frame_number, cell_types):
+        self._cell_types[frame_number - 1] = cell_types
+
+    def get_cell_types(self, frame_number):
+        return self._cell_types[frame_number - 1]
+
+    def load_labels_from_external_file_array(self, frame, image):
+        """ti.py:3467-3472 without the TIFF read: labels = label(image, background=255, connectivity=1)."""
+        labels = seg.label(image, background=255, connectivity=1)
+        self.set_labels(frame, labels, reset_data=True)
+        return labels
