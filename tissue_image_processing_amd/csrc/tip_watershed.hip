@@ -21,6 +21,7 @@
 // tie-break (label IoU vs the reference is reported by the tests).
 #include "tip_internal.h"
 #include "tip_uf.h"
+#include <cstdlib>
 
 namespace tip {
 
@@ -52,13 +53,17 @@ struct WsInfo {           // device-resident scalars
     int n_markers;
     int changed, undecided;          // per-iteration counters (mode A) / frontier, pending (mode B)
     unsigned long long fb_v, fb_k;   // fallback reduction
+    unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
 };
 
 __global__ void __launch_bounds__(256) k_ws_minmax(const double *__restrict__ v, long n, WsInfo *info)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long lo = ~0ULL, hi = 0ULL;
-    if (i < n) { lo = hi = enc_f64(v[i]); }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long e = enc_f64(v[i]);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+    }
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
         lo = l2 < lo ? l2 : lo;
@@ -69,11 +74,14 @@ __global__ void __launch_bounds__(256) k_ws_minmax(const double *__restrict__ v,
 
 __global__ void __launch_bounds__(256) k_ws_count_other(const double *__restrict__ v, long n, WsInfo *info)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int c = 0;
-    if (i < n) { const unsigned long long e = enc_f64(v[i]); c = (e != info->emin && e != info->emax); }
-    const unsigned long long m = __ballot(c);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&info->n_other, (unsigned long long)__popcll(m));
+    const unsigned long long emin = info->emin, emax = info->emax;
+    unsigned long long c = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long e = enc_f64(v[i]);
+        c += (e != emin && e != emax);
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&info->n_other, c);
 }
 
 // ---- markers: label(local_minima(image)) ---------------------------------------------------------------------------
@@ -130,81 +138,86 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 
 // ---- mode A: tile-local rounds ------------------------------------------------------------------------------------------
 constexpr int WT = 32;           // tile interior
-constexpr int WH = 5;            // halo (pocket flood needs p +- 5)
-constexpr int WL = WT + 2 * WH;  // 42
+// Two launch flavours: the everyday one certifies pockets of up to 6 cells inside a 3-pixel halo; when a whole
+// launch makes no progress the wide one (12-pixel halo, 48-cell pockets: stuck pockets are thin staircases up to
+// ~10 px long on smooth landscapes) is tried before the global-minimum fallback.
+constexpr int WH_FAST = 3, WK_FAST = 6;
+constexpr int WH_WIDE = 12, WK_WIDE = 48;
 constexpr int LINE_LAB = -1;
 
 struct T2 { double v; int i; };
 __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
 
 struct TileView {
-    const double *sv, *stv;
-    const int *slab, *sti;
-    int gy0, gx0, X;  // global coords of local (0,0)
-    __device__ __forceinline__ int gidx(int c) const { return (gy0 + c / WL) * X + gx0 + c % WL; }
-    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], gidx(c)}; }
-    __device__ __forceinline__ T2 T(int c) const { return T2{stv[c], sti[c]}; }
+    const double *sv;       // LDS: image values of the window
+    const int *slab, *sti;  // LDS: label / 0 / LINE, and pop-time reference pixel (global index) of labelled cells
+    const int *sgi;         // LDS: global linear index of every window cell
+    const double *gv;       // global image (pop-time value of pulled pixels = gv[tref])
+    unsigned short *vis;    // LDS: this thread's pocket list
+    int budget;             // pocket flood budget (cells)
+    int WL;                 // window edge (tile + 2 * halo)
+    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], sgi[c]}; }
+    __device__ __forceinline__ T2 T(int c) const
+    {
+        const int tr = sti[c];
+        return T2{tr == sgi[c] ? sv[c] : gv[tr], tr};
+    }
 };
 
 // Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
-// key < t around q inside a 7x7 window (bit masks, no scratch); it is closed iff nothing labelled before t touches it.
-__device__ bool ws_cert(const TileView &tv, int q, int asker, const T2 &t)
+// key < t around q (breadth first, the per-thread list in LDS is queue and visited set at once); the pocket is closed
+// iff nothing labelled before t touches it.  Running out of budget or window is "cannot certify" (the pixel waits).
+__device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, const T2 &t)
 {
-    const int qy = q / WL, qx = q % WL;
-    auto bit = [&](int c) -> int {
-        const int dy = c / WL - qy + 3, dx = c % WL - qx + 3;
-        return (dy < 0 || dy > 6 || dx < 0 || dx > 6) ? -1 : dy * 7 + dx;
-    };
-    unsigned long long seen = 1ULL << 24, todo = 1ULL << 24;  // (3,3) = q
-    {
-        const int b = bit(asker);
-        if (b >= 0) seen |= 1ULL << b;
-    }
-    int pops = 0;
-    while (todo) {
-        const int b = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        if (++pops > 32) return false;
-        const int c = (qy + b / 7 - 3) * WL + (qx + b % 7 - 3);
-        const int nb[4] = {c - WL, c - 1, c + 1, c + WL};
+    int nv = 1, head = 0;
+    const int WL = tv.WL;
+    tv.vis[0] = (unsigned short)q;
+    while (head < nv) {
+        const int c = tv.vis[head++];
+        const int cy = c / WL, cx = c - cy * WL;
+        if (cy == 0 || cy == WL - 1 || cx == 0 || cx == WL - 1) return false;  // neighbours outside the window
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int m = nb[k];
+            const int m = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
             if (m == asker) continue;
             const int l = tv.slab[m];
             if (l == LINE_LAB) continue;
             if (l > 0) {
                 if (t_lt(tv.T(m), t)) return false;
             } else if (t_lt(tv.key(m), t)) {
-                const int mb = bit(m);
-                if (mb < 0) return false;  // pocket leaves the window: cannot certify
-                if (!((seen >> mb) & 1ULL)) { seen |= 1ULL << mb; todo |= 1ULL << mb; }
+                bool seen = false;
+                for (int j = 0; j < nv; ++j) seen |= tv.vis[j] == (unsigned short)m;
+                if (!seen) {
+                    if (nv >= tv.budget) return false;
+                    tv.vis[nv++] = (unsigned short)m;
+                }
             }
         }
     }
     return true;
 }
 
-struct Decision { int lab; double tv; int ti; };  // lab == 0: no decision
+struct Decision { int lab; int ti; };  // lab == 0: no decision; ti = pop-time reference pixel
 
-__device__ Decision ws_decide(const TileView &tv, int c, bool force)
+// certs == false: cheap rule, any undecided neighbour that could pop earlier makes the pixel wait (the common case:
+// that neighbour is simply not processed yet).  certs == true: such neighbours are examined with ws_cert, which is what
+// resolves genuinely stuck pockets; the tile loop only asks for it after a round without progress.
+__device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool certs)
 {
-    Decision d{0, 0.0, 0};
-    const int nb[4] = {c - WL, c - 1, c + 1, c + WL};
-    bool haslab = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) haslab |= tv.slab[nb[k]] > 0;
-    if (!haslab) return d;
+    Decision d{0, 0};
+    const int WL = tv.WL;
+    const int l0 = tv.slab[c - WL], l1 = tv.slab[c - 1], l2 = tv.slab[c + 1], l3 = tv.slab[c + WL];
+    if (!(l0 > 0 || l1 > 0 || l2 > 0 || l3 > 0)) return d;
     const T2 kp = tv.key(c);
     int s_lab = 0;
-    bool conflict = false, has_pull = false;
+    bool conflict = false, has_pull = false, wait = false;
     T2 pull_t{0.0, 0};
     int pull_lab = 0;
     unsigned und_mask = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int q = nb[k];
-        const int l = tv.slab[q];
+        const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+        const int l = k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));
         if (l == LINE_LAB) continue;
         if (l > 0) {
             const T2 tq = tv.T(q);
@@ -216,39 +229,46 @@ __device__ Decision ws_decide(const TileView &tv, int c, bool force)
             }
         } else {
             und_mask |= 1u << k;
-            if (!force && t_lt(tv.key(q), kp) && !ws_cert(tv, q, c, kp)) return d;
+            if (t_lt(tv.key(q), kp)) {
+                if (!certs) wait = true;
+                else if (!ws_cert(tv, q, c, kp)) wait = true;
+            }
         }
     }
+    if (wait) return d;
     if (s_lab != 0) {
         d.lab = conflict ? LINE_LAB : s_lab;
-        d.tv = kp.v; d.ti = kp.i;
+        d.ti = kp.i;
         return d;
     }
     if (!has_pull) return d;
-    if (!force) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!((und_mask >> k) & 1u)) continue;
-            const int q = nb[k];
-            if (t_lt(pull_t, tv.key(q))) continue;
-            if (!ws_cert(tv, q, c, pull_t)) return d;
-        }
+    for (int k = 0; k < 4; ++k) {
+        if (!((und_mask >> k) & 1u)) continue;
+        const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+        if (t_lt(pull_t, tv.key(q))) continue;
+        if (!certs) return d;
+        if (!ws_cert(tv, q, c, pull_t)) return d;
     }
-    d.lab = pull_lab; d.tv = pull_t.v; d.ti = pull_t.i;
+    d.lab = pull_lab; d.ti = pull_t.i;
     return d;
 }
 
+template <int WH, int WK>
 __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
                                                   unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
                                                   int first, int max_rounds, WsInfo *info)
 {
+    constexpr int WL = WT + 2 * WH;
     __shared__ double sv[WL * WL];
-    __shared__ double stv[WL * WL];
     __shared__ int slab[WL * WL];
     __shared__ int sti[WL * WL];
-    __shared__ int s_any;
+    __shared__ int sgi[WL * WL];
+    __shared__ unsigned short svis[256 * WK];
+    __shared__ int s_any[2], s_und;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
+    if (first == 2 && tile_und[tile] == 0) return;  // wide pass: every tile that still has undecided pixels
     if (!first) {
         if (tile_und[tile] == 0) return;
         bool act = false;
@@ -261,72 +281,66 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
     for (int c = threadIdx.x; c < WL * WL; c += 256) {
-        const int gy = gy0 + c / WL, gx = gx0 + c % WL;
+        const int ly = c / WL, lx = c - ly * WL;
+        const int gy = gy0 + ly, gx = gx0 + lx;
         if (gy < 0 || gy >= Y || gx < 0 || gx >= X) {
-            slab[c] = LINE_LAB; sv[c] = 0.0; stv[c] = 0.0; sti[c] = 0;
+            slab[c] = LINE_LAB; sv[c] = 0.0; sti[c] = 0; sgi[c] = -1;
         } else {
             const int gi = gy * X + gx;
             const unsigned long long s = st[gi];
-            const int l = st_lab(s), tr = st_tref(s);
-            const double val = v[gi];
-            sv[c] = val; slab[c] = l; sti[c] = tr;
-            stv[c] = l > 0 ? (tr == gi ? val : v[tr]) : 0.0;
+            sv[c] = v[gi]; slab[c] = st_lab(s); sti[c] = st_tref(s); sgi[c] = gi;
         }
     }
-    if (threadIdx.x == 0) s_any = 0;
+    if (threadIdx.x == 0) { s_any[0] = 0; s_any[1] = 0; s_und = 0; }
     __syncthreads();
-    TileView tv{sv, stv, slab, sti, gy0, gx0, X};
+    TileView tv{sv, slab, sti, sgi, v, svis + threadIdx.x * WK, WK, WL};
     int cells[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = threadIdx.x + k * 256;
         cells[k] = (p / WT + WH) * WL + (p % WT + WH);
     }
-    int my_changes = 0;
+    int my_changes = 0, my_evals = 0, my_rounds = 0;
+    bool certs = false;
     for (int round = 0; round < max_rounds; ++round) {
+        my_rounds++;
         Decision dec[4];
         bool any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             dec[k].lab = 0;
             if (slab[cells[k]] == 0) {
-                dec[k] = ws_decide(tv, cells[k], false);
+                my_evals++;
+                dec[k] = ws_decide(tv, cells[k], certs);
                 any |= dec[k].lab != 0;
             }
         }
-        __syncthreads();
-        if (any) s_any = 1;
+        __syncthreads();  // every read of this round is done
+        if (threadIdx.x == 0) s_any[(round + 1) & 1] = 0;
+        if (any) s_any[round & 1] = 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (dec[k].lab != 0) {
-                slab[cells[k]] = dec[k].lab; stv[cells[k]] = dec[k].tv; sti[cells[k]] = dec[k].ti;
+                slab[cells[k]] = dec[k].lab; sti[cells[k]] = dec[k].ti;
                 my_changes++;
             }
         __syncthreads();
-        const int go = s_any;
-        __syncthreads();
-        if (!go) break;
-        if (threadIdx.x == 0) s_any = 0;
-        // (the next round's first barrier orders this reset before any new set)
+        if (s_any[round & 1]) { certs = false; continue; }
+        if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
+        certs = true;       // local stall: one round with pocket certificates
     }
     int und = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = cells[k];
-        const int gy = gy0 + c / WL, gx = gx0 + c % WL;
-        if (gy < Y && gx < X) {
+        const int gi = sgi[c];
+        if (gi >= 0) {
             const int l = slab[c];
             if (l == 0) und++;
-            else {
-                const int gi = gy * X + gx;
-                if (st_lab(st[gi]) == 0) st[gi] = pack_st(l, sti[c]);
-            }
+            else if (st_lab(st[gi]) == 0) st[gi] = pack_st(l, sti[c]);
         }
     }
     const int tot_changes = __syncthreads_count(my_changes > 0);
-    __shared__ int s_und;
-    if (threadIdx.x == 0) s_und = 0;
-    __syncthreads();
     if (und) atomicAdd(&s_und, und);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -334,7 +348,10 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
         changed_cur[tile] = tot_changes > 0;
         if (tot_changes > 0) atomicAdd(&info->changed, tot_changes);
         if (s_und) atomicAdd(&info->undecided, s_und);
+        atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
+        atomicAdd(&info->dbg_tiles, 1ULL);
     }
+    if (my_evals) atomicAdd(&info->dbg_evals, (unsigned long long)my_evals);
 }
 
 // fallback: the undecided pixel with the globally smallest pop time is always safe to commit
@@ -488,8 +505,13 @@ __global__ void k_ws_info_init(WsInfo *info)
 {
     info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
     info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
 }
-__global__ void k_ws_iter_reset(WsInfo *info) { info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL; }
+__global__ void k_ws_iter_reset(WsInfo *info)
+{
+    info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
+}
 
 int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int32_t *flags_host)
 {
@@ -506,8 +528,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     if (!info || !parent || !flag || !isroot || !rank || !st) return TIP_ERR_NOMEM;
     hipStream_t s = c.stream;
     TIP_LAUNCH("ws_info_init", k_ws_info_init, dim3(1), dim3(1), 0, info);
-    TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(cdiv(n, 256)), dim3(256), 0, img, n, info);
-    TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(cdiv(n, 256)), dim3(256), 0, img, n, info);
+    TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(min(1024, cdiv(n, 256))), dim3(256), 0, img, n, info);
+    TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(min(1024, cdiv(n, 256))), dim3(256), 0, img, n, info);
     // markers
     SameF64 same{img};
     int rc = uf_components(same, parent, Y, X);
@@ -554,16 +576,23 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (!chg || !tile_und) return TIP_ERR_NOMEM;
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
         int iter = 0, fallbacks = 0;
+        bool wide = false;
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
             TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
-            TIP_LAUNCH("ws_tiles", k_ws_tiles, dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX, tilesY,
-                       (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+            if (!wide)
+                TIP_LAUNCH("ws_tiles", (k_ws_tiles<WH_FAST, WK_FAST>), dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX, tilesY,
+                           (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+            else
+                TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WH_WIDE, WK_WIDE>), dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX,
+                           tilesY, (const unsigned char *)prev, cur, tile_und, 2, 4096, info);
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
-            if (h.changed > 0) continue;
-            // no tile made progress: either done, or pockets too large to certify locally -> commit the global minimum
+            if (getenv("TIP_WS_DEBUG"))
+                fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d\n", iter, wide ? "wide" : "fast",
+                        h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed);
+            if (h.changed > 0) { wide = false; continue; }
             long und_total = 0;
             {
                 std::vector<int> hu(ntiles);
@@ -572,6 +601,9 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 for (int v2 : hu) und_total += v2;
             }
             if (und_total == 0) break;
+            if (!wide) { wide = true; continue; }  // no progress with small pockets: one wide launch over every tile
+            wide = false;
+            // still nothing: pockets too large to certify locally -> commit the pixel with the globally smallest pop time
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             TIP_LAUNCH("ws_fb_min1", k_ws_fb_min1, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
             TIP_LAUNCH("ws_fb_min2", k_ws_fb_min2, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
@@ -580,8 +612,12 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_HIP(hipStreamSynchronize(s));
             if (h.fb_k == ~0ULL) break;  // the remaining pixels are enclosed by lines: they stay 0, as in the serial flood
             fallbacks++;
-            // wake every tile up again
-            TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+            // wake the tile of the committed pixel (its 3x3 neighbourhood follows through the activity rule)
+            {
+                const int pi = (int)(unsigned)(h.fb_k & 0xffffffffULL);
+                const int t = (pi / X / WT) * tilesX + (pi % X) / WT;
+                TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles + t, 1, 1, s));
+            }
         }
         flags |= (fallbacks & 0x3fff) << 2;
     }

@@ -54,6 +54,32 @@ class FramePipeline:
             _lib.dptr(img), _lib.dptr(self.d_labels.ptr), self.Y, self.X, ctypes.c_double(self.imgthresh),
             _lib.ptr(self.tseg), self.tseg.size, self.block, ctypes.byref(self.flags)))
 
+    def cell_tables(self, max_cells=None):
+        """C1-C2 (ti.py:880-909, 1815-1842): per-cell reductions + neighbour pairs on the resident label map; the small
+        per-cell arrays come back to the host (they are what a rank gathers for track stitching)."""
+        P = self.Y * self.X
+        cap_cells = max_cells or max(1024, P // 64)
+        if getattr(self, "_tables", None) is None or self._tables[0] < cap_cells:
+            n = cap_cells
+            self._tables = (n, _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 32), _lib.DeviceBuffer(n * 8),
+                            _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 24), _lib.DeviceBuffer(16 * n * 8))
+        n, d_area, d_bbox, d_sy, d_sx, d_pc, d_pairs = self._tables
+        _lib.check(self.lib.tip_regionprops_i32_dev(_lib.dptr(self.d_labels.ptr), None, self.Y, self.X, n,
+                                                    _lib.dptr(d_area.ptr), _lib.dptr(d_bbox.ptr), _lib.dptr(d_sy.ptr),
+                                                    _lib.dptr(d_sx.ptr), _lib.dptr(d_pc.ptr), None))
+        npairs = ctypes.c_int64(0)
+        _lib.check(self.lib.tip_neighbor_pairs_i32_dev(_lib.dptr(self.d_labels.ptr), self.Y, self.X,
+                                                       _lib.dptr(d_pairs.ptr), ctypes.c_int64(16 * n),
+                                                       ctypes.byref(npairs)))
+        area = d_area.download((n,), np.int64)
+        ncells = int(np.max(np.nonzero(area)[0])) + 1 if area.any() else 0
+        self.tables = dict(
+            area=area[:ncells], bbox=d_bbox.download((n, 4), np.int64)[:ncells],
+            sumy=d_sy.download((n,), np.int64)[:ncells], sumx=d_sx.download((n,), np.int64)[:ncells],
+            pc=d_pc.download((n, 3), np.int64)[:ncells],
+            pairs=d_pairs.download((16 * n, 2), np.int32)[:npairs.value])
+        return self.tables
+
     def sync(self):
         _lib.check(self.lib.tip_sync())
 
