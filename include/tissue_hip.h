@@ -131,6 +131,10 @@ TIP_API int tip_neighbor_pairs_i32_dev(const int32_t *labels, int y, int x, int3
                                        int64_t *n_pairs_host);
 /* Tissue.update_labels (ti.py:2967-2970): negatives take the zero-padded 3x3 maximum              */
 TIP_API int tip_update_labels_i32(int32_t *labels, int y, int x);
+/* track_cells_iterator's label lookup (ti.py:2081-2090): maximum_filter(labels,(3,3),'constant') sampled at query   */
+/* points (host arrays); out[i] = -1 for points outside the frame. labels is a DEVICE pointer.                     */
+TIP_API int tip_lookup_max3_i32_dev(const int32_t *labels, int y, int x, const int64_t *qy_host, const int64_t *qx_host,
+                                    int64_t n, int32_t *out_host);
 /* Tissue.get_trackking_labels (ti.py:4021-4028): out[p] = lut[labels[p]] (lut[0] = 0)              */
 TIP_API int tip_lut_gather_i32(const int32_t *labels, const int64_t *lut, int64_t n_lut, int64_t *out, int64_t n);
 

@@ -101,13 +101,13 @@ def blur_image(image, std):
 # ----------------------------------------------------------------------------- percentile (sp.py:33-36)
 def percentile_linear(a, q):
     """np.percentile(a, q) for a 1-D float array with numpy 1.26.4 arithmetic (the oracle interpreter):
-    virtual index n*q' + (1 - q') - 1 with q' = q/100, previous/next order statistics, and
+    virtual index (n-1)*q' with q' = q/100, previous/next order statistics, and
     _lerp: a + (b-a)*t, replaced by b - (b-a)*(1-t) when t >= 0.5; (b-a) is formed in the array dtype,
     the rest in float64.  Returns a float64 scalar."""
     a = np.sort(np.ravel(a))
     n = a.size
     quant = np.true_divide(q, 100)
-    virtual = n * quant + (1 + quant * (1 - 1 - 1)) - 1
+    virtual = (n - 1) * quant  # numpy's 'linear' method: get_virtual_index = (n - 1) * quantiles
     prev = int(np.floor(virtual))
     gamma = np.float64(virtual - prev)
     prev = min(max(prev, 0), n - 1)

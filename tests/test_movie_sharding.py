@@ -1,0 +1,60 @@
+"""Multi-process (gloo, world_size 2) test of the frame-sharded movie driver and its track stitching, on CPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, out, n_rep=1):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_movie_worker.py"), out, str(n_rep)],
+                                      env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+
+
+def test_frames_for_rank():
+    from tissue_image_processing_amd.pipeline import frames_for_rank
+    assert frames_for_rank(7, 0, 2) == [0, 2, 4, 6]
+    assert frames_for_rank(7, 1, 2) == [1, 3, 5]
+    assert sorted(sum((frames_for_rank(200, r, 8) for r in range(8)), [])) == list(range(200))
+
+
+def test_single_process_matches_reference_tracker(golden):
+    """world=1 driver == the reference's track_cells_iterator ids (golden from the reference itself)."""
+    from _movie_worker import OracleBackend
+    from tissue_image_processing_amd import movie
+    g = golden("tracking")
+    labs = list(g["labels"])
+    drifts = np.zeros((3, 2))
+    drifts[1:] = (0.5, -0.3)
+    tabs, ids = movie.process_movie(3, lambda t: labs[t], OracleBackend(), 0, 1, None, "cpu", drifts)
+    for t in range(3):
+        np.testing.assert_array_equal(ids[t], g["ids_%d" % t])
+
+
+def test_world2_gloo_equals_world1(tmp_path):
+    out1, out2 = str(tmp_path / "w1.npz"), str(tmp_path / "w2.npz")
+    _run(1, out1)
+    _run(2, out2)
+    a, b = np.load(out1), np.load(out2)
+    assert int(a["n"]) == int(b["n"]) == 6
+    for t in range(int(a["n"])):
+        np.testing.assert_array_equal(a["ids_%d" % t], b["ids_%d" % t])

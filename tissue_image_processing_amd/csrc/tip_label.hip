@@ -249,6 +249,26 @@ __global__ void __launch_bounds__(256) k_lut_gather(const int32_t *__restrict__ 
     out[i] = lut[l];
 }
 
+// T3 lookup (ti.py:2081-2090): value of maximum_filter(labels, (3,3), mode='constant') at rounded query points
+__global__ void __launch_bounds__(256) k_lookup_max3(const int32_t *__restrict__ lab, int Y, int X, const int64_t *__restrict__ qy,
+                                                     const int64_t *__restrict__ qx, long n, int32_t *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long y = qy[i], x = qx[i];
+    if (y < 0 || y >= Y || x < 0 || x >= X) { out[i] = -1; return; }  // invalid location (ti.py:2086-2087)
+    int32_t best = 0;
+    bool have = false;
+    for (int j = -1; j <= 1; ++j)
+        for (int k = -1; k <= 1; ++k) {
+            const long yy = y + j, xx = x + k;
+            const int32_t q = (yy < 0 || yy >= Y || xx < 0 || xx >= X) ? 0 : lab[yy * X + xx];
+            if (!have) { best = q; have = true; }
+            else if (q > best) best = q;
+        }
+    out[i] = best;
+}
+
 }  // namespace tip
 
 using namespace tip;
@@ -328,6 +348,27 @@ int tip_update_labels_i32(int32_t *labels, int y, int x)
     TIP_HIP(hipMemcpyAsync(din, labels, bytes, hipMemcpyHostToDevice, c.stream));
     TIP_LAUNCH("update_labels", k_update_labels, dim3(cdiv(x, 256), y), dim3(256), 0, (const int32_t *)din, dout, y, x);
     TIP_HIP(hipMemcpyAsync(labels, dout, bytes, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_lookup_max3_i32_dev(const int32_t *labels, int y, int x, const int64_t *qy_host, const int64_t *qx_host, int64_t n,
+                            int32_t *out_host)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!labels || y < 1 || x < 1 || n < 0) return fail(TIP_ERR_ARG, "tip_lookup_max3_i32_dev: bad arguments");
+    if (n == 0) return TIP_OK;
+    if (!qy_host || !qx_host || !out_host) return fail(TIP_ERR_ARG, "tip_lookup_max3_i32_dev: null pointer");
+    WsGuard ws;
+    int64_t *dy = ws.get<int64_t>(n), *dx = ws.get<int64_t>(n);
+    int32_t *dout = ws.get<int32_t>(n);
+    if (!dy || !dx || !dout) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(dy, qy_host, n * 8, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipMemcpyAsync(dx, qx_host, n * 8, hipMemcpyHostToDevice, c.stream));
+    TIP_LAUNCH("lookup_max3", k_lookup_max3, dim3(cdiv(n, 256)), dim3(256), 0, labels, y, x, (const int64_t *)dy,
+               (const int64_t *)dx, (long)n, dout);
+    TIP_HIP(hipMemcpyAsync(out_host, dout, n * 4, hipMemcpyDeviceToHost, c.stream));
     TIP_HIP(hipStreamSynchronize(c.stream));
     return TIP_OK;
 }

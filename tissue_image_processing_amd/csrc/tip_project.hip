@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long 
         return;
     }
     const double quant = 95.0 / 100.0;
-    const double virt = (double)n * quant + (1.0 + quant * (1.0 - 1.0 - 1.0)) - 1.0;
+    const double virt = (double)(n - 1) * quant;  // numpy 'linear': (n - 1) * quantiles
     double fl = floor(virt);
     const double gamma = virt - fl;
     long long prev = (long long)fl;

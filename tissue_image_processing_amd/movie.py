@@ -1,0 +1,181 @@
+"""Frame-sharded time-lapse processing: one process per GPU, frame t -> rank t % world.
+
+Every per-frame stage (projection, segmentation, cell tables) is independent, so the data path needs no
+collective.  The one exchange step is track stitching (tissue_info.track_cells_iterator, ti.py:2037-2113):
+
+  1. all ranks all-gather the small per-frame centroid tables (cy, cx; a few thousand rows per frame);
+  2. the rank that owns frame t looks the drift-corrected centroids of frame t-1 up in ITS resident label map
+     (3x3 max-filtered, ti.py:2081) -- the only dense-array part of the tracker stays next to the data;
+  3. the resulting index arrays (one int per cell) are gathered to rank 0 (RCCL gather = grouped send/recv over
+     xGMI, a direct all-to-one, KBs per frame), which runs the sequential id propagation.
+
+`backend` supplies the per-frame compute so the same driver runs on GPUs (GpuFrameBackend) and, for the
+multi-process CPU tests, on a stand-in backend with the gloo process group.
+"""
+import numpy as np
+
+
+class GpuFrameBackend(object):
+    """Per-frame compute on this rank's MI355X through FramePipeline; label maps stay resident per owned frame."""
+
+    def __init__(self, C, Z, Y, X, device=None, **kw):
+        from .pipeline import FramePipeline
+        self.pipe = FramePipeline(C, Z, Y, X, device=device, **kw)
+        self.Y, self.X = Y, X
+        self.labels = {}   # frame -> DeviceBuffer (int32 label map)
+
+    def process_frame(self, t, stack_u16):
+        from . import _lib
+        p = self.pipe
+        d_stack = p.upload_stack(stack_u16)
+        p.project(d_stack)
+        p.segment(0)
+        tab = p.cell_tables()
+        d_stack.free()
+        keep = _lib.DeviceBuffer(self.Y * self.X * 4)
+        _lib.check(p.lib.tip_sync())
+        lab = p.fetch_labels()
+        keep.upload(lab)
+        self.labels[t] = keep
+        area = tab["area"].astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cy = tab["sumy"] / area
+            cx = tab["sumx"] / area
+        return dict(area=tab["area"], cy=np.where(area > 0, cy, 0.0), cx=np.where(area > 0, cx, 0.0))
+
+    def lookup(self, t, qy, qx):
+        from . import _lib
+        qy = np.ascontiguousarray(qy, dtype=np.int64)
+        qx = np.ascontiguousarray(qx, dtype=np.int64)
+        out = np.empty(qy.shape, np.int32)
+        _lib.check(self.pipe.lib.tip_lookup_max3_i32_dev(_lib.dptr(self.labels[t].ptr), self.Y, self.X, _lib.ptr(qy),
+                                                          _lib.ptr(qx), qy.size, _lib.ptr(out)))
+        return out
+
+
+def _all_gather_arrays(arrs, dist, world, device):
+    """all-gather a list of float64 1-D arrays of per-rank varying length -> list (per rank) of arrays."""
+    import torch
+    flat = np.concatenate([np.asarray(a, np.float64).ravel() for a in arrs]) if arrs else np.zeros(0)
+    n = torch.tensor([flat.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.float64, device=device)
+    buf[:flat.size] = torch.from_numpy(flat).to(device)
+    out = [torch.zeros(m, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
+
+
+def _gather_to_root(flat, dist, rank, world, device):
+    """gatherv of an int64 array to rank 0 (counts all-gathered first, then one padded gather)."""
+    import torch
+    flat = np.asarray(flat, np.int64).ravel()
+    n = torch.tensor([flat.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.int64, device=device)
+    buf[:flat.size] = torch.from_numpy(flat).to(device)
+    out = [torch.zeros(m, dtype=torch.int64, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
+
+
+def propagate_ids(tables, lookups):
+    """Sequential part of track_cells_iterator (ti.py:2041-2110) on rank 0.
+
+    tables[t]: dict(area, cy, cx) over row index = label-1; lookups[t] (t >= 1): for every row of frame t-1 the value
+    of the 3x3-max-filtered label map of frame t at its drift-corrected centroid (-1 = outside).  Returns the
+    per-frame id arrays exactly as the reference leaves them in cells_info.label."""
+    n0 = tables[0]["area"].size
+    # calculate_frame_cellinfo leaves label = row+1 for present rows, 0 for absent ones (ti.py:893)
+    ids0 = np.where(tables[0]["area"] > 0, np.arange(1, n0 + 1), 0).astype(np.int64)
+    unl = ids0 == 0
+    last = ids0.max() if n0 else 0
+    ids0[unl] = np.arange(last + 1, last + unl.sum() + 1)
+    out = [ids0]
+    ids_prev = ids0
+    for t in range(1, len(tables)):
+        n_cur = tables[t]["area"].size
+        ids = np.zeros(n_cur, np.int64)
+        idx = lookups[t].astype(np.float64) - 1
+        idx[lookups[t] < 0] = -1
+        lp = ids_prev[idx >= 0]
+        idx = idx[idx >= 0]
+        _, loc = np.unique(lp, return_index=True)
+        idx, lp = idx[loc], lp[loc]
+        _, loc = np.unique(idx, return_index=True)
+        idx, lp = idx[loc], lp[loc]
+        ids[idx.astype(int)] = lp
+        unl = ids == 0
+        last = ids.max() if n_cur else 0
+        ids[unl] = np.arange(last + 1, last + unl.sum() + 1)
+        out.append(ids)
+        ids_prev = ids
+    return out
+
+
+def process_movie(n_frames, frame_source, backend, rank=0, world=1, dist=None, device="cpu", drifts=None):
+    """Runs the sharded pipeline.  frame_source(t) -> uint16 stack (or whatever backend.process_frame takes).
+    Returns on rank 0: (tables per frame, track ids per frame); on other ranks (None, None)."""
+    if drifts is None:
+        drifts = np.zeros((n_frames, 2))
+    mine = list(range(rank, n_frames, world))
+    local = {t: backend.process_frame(t, frame_source(t)) for t in mine}
+    # 1. centroid tables everywhere
+    if world > 1:
+        payload = []
+        for t in mine:
+            tb = local[t]
+            payload += [np.array([t, tb["area"].size], np.float64), tb["area"].astype(np.float64), tb["cy"], tb["cx"]]
+        gathered = _all_gather_arrays(payload, dist, world, device)
+        tables = {}
+        for flat in gathered:
+            pos = 0
+            while pos < flat.size:
+                t, n = int(flat[pos]), int(flat[pos + 1])
+                pos += 2
+                tables[t] = dict(area=flat[pos:pos + n].astype(np.int64), cy=flat[pos + n:pos + 2 * n],
+                                 cx=flat[pos + 2 * n:pos + 3 * n])
+                pos += 3 * n
+    else:
+        tables = local
+    # 2. owners look previous centroids up in their resident label maps
+    my_lookups = {}
+    for t in mine:
+        if t == 0:
+            continue
+        prev = tables[t - 1]
+        cy = prev["cy"] - drifts[t][0]
+        cx = prev["cx"] - drifts[t][1]
+        qy, qx = np.round(cy).astype(np.int64), np.round(cx).astype(np.int64)
+        res = backend.lookup(t, qy, qx)
+        res = np.where(prev["area"] > 0, res, -1)   # absent rows never match (empty_cell / zero-area rows)
+        my_lookups[t] = res
+    # 3. gather to rank 0
+    if world > 1:
+        flat = []
+        for t, r in my_lookups.items():
+            flat += [np.array([t, r.size], np.int64), r.astype(np.int64)]
+        flat = np.concatenate(flat) if flat else np.zeros(0, np.int64)
+        parts = _gather_to_root(flat, dist, rank, world, device)
+        if rank != 0:
+            return None, None
+        lookups = {}
+        for p in parts:
+            pos = 0
+            while pos < p.size:
+                t, n = int(p[pos]), int(p[pos + 1])
+                lookups[t] = p[pos + 2:pos + 2 + n]
+                pos += 2 + n
+    else:
+        lookups = my_lookups
+    tabs = [tables[t] for t in range(n_frames)]
+    ids = propagate_ids(tabs, [None] + [lookups[t] for t in range(1, n_frames)])
+    return tabs, ids

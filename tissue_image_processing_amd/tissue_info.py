@@ -189,7 +189,7 @@ class TissueHipMixin(object):
         starts = np.searchsorted(sl, cell_indices + 1, side="left")
         counts = rp["area"][cell_indices]
         q = (100 - percentage_above_threshold) / 100.0
-        virt = counts * q + (1 + q * (1 - 1 - 1)) - 1
+        virt = (counts - 1) * q
         prev = np.clip(np.floor(virt).astype(np.int64), 0, counts - 1)
         nxt = np.minimum(prev + 1, counts - 1)
         gamma = virt - np.floor(virt)
