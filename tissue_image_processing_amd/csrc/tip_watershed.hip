@@ -1,7 +1,7 @@
 // tip_watershed.hip -- skimage.segmentation.watershed(image, markers=None, connectivity=1, watershed_line=True)
 // (reference call sites bim.py:475 and pl.py:194) as a data-parallel flood.
 //
-// The serial algorithm (skimage/segmentation/_watershed_cy.pyx, restated in oracle/tip_oracle.c) pops pixels from
+// The serial algorithm (skimage/segmentation/_watershed_cy.pyx, restated for the tests under oracle/) pops pixels from
 // a (value, age) heap.  What decides a pixel's fate is only WHICH OF ITS NEIGHBOURS WERE LABELLED BEFORE IT POPS:
 //   * a pixel pops at time T = (value, index) -- or, if every lower neighbour is a watershed line, right after the
 //     first neighbour that gets labelled later ("pulled", it then inherits that neighbour's pop time and label);
