@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
-    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,7 +92,11 @@ def main():
 
     # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
     st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
-    pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False)
+    pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(workload == "unet"))
+    predictor = None
+    if workload == "unet":
+        from tissue_image_processing_amd.prediction_local import SegmentationPredictor
+        predictor = SegmentationPredictor(None, (2, X, Y), device=local_rank)  # random-init weights (none ship upstream)
     frames = [pipe.upload_stack(st), pipe.upload_stack(np.ascontiguousarray(st[:, :, :, ::-1]))]
     del st
 
@@ -101,6 +105,9 @@ def main():
         if workload == "classical":
             pipe.segment(0)
             pipe.cell_tables()
+        elif workload == "unet":
+            lab, _ = pipe.segment_unet(predictor)
+            pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
 
     def barrier():
         if world > 1:
@@ -154,7 +161,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, {
                 "projection": "surface_projection",
-                "classical": "surface_projection+watershed_segmentation+cell_tables"}[workload]),
+                "classical": "surface_projection+watershed_segmentation+cell_tables",
+                "unet": "surface_projection+unet_segmentation(%s,random-init)+cell_tables" % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}[workload]),
                 "frames_per_step": world, "parallelism": "frame-sharded dp%d, no data-path collective" % world},
             "roofline": roof, "kernels": kernels,
         }

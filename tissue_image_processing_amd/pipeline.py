@@ -16,7 +16,7 @@ class FramePipeline:
     """Keeps one frame's buffers resident in HBM between stages (inputs uploaded once, outputs fetched on demand)."""
 
     def __init__(self, C, Z, Y, X, reference_channel=0, airyscan=False, atoh_shift=0,
-                 imgthresh=0.03, stdeviation=3.0, blocksize=3, device=None):
+                 imgthresh=0.03, stdeviation=3.0, blocksize=3, device=None, use_torch=False):
         if device is not None:
             _lib.init(device)
         self.lib = _lib.lib()
@@ -26,7 +26,19 @@ class FramePipeline:
         self.t05, self.t1, self.t2, self.t30 = (gaussian_taps(s) for s in (0.5, 1.0, 2.0, 30.0))
         self.tseg = gaussian_taps(stdeviation)
         P = Y * X
-        self.d_proj = _lib.DeviceBuffer(C * P * 8)
+        self._proj_t = None
+        if use_torch:  # projection buffer owned by torch so that the U-Net path consumes it without a copy
+            import torch
+
+            class _View(object):
+                pass
+            dev = torch.device("cuda", _lib.device_for_thread() or 0)
+            self._proj_t = torch.empty((C, Y, X), dtype=torch.float64, device=dev)
+            self.d_proj = _View()
+            self.d_proj.ptr = self._proj_t.data_ptr()
+            self.d_proj.download = lambda shape, dtype, t=self._proj_t: t.cpu().numpy()
+        else:
+            self.d_proj = _lib.DeviceBuffer(C * P * 8)
         self.d_zmap = _lib.DeviceBuffer(P * 8)
         self.d_labels = _lib.DeviceBuffer(P * 4)
         self.flags = ctypes.c_int32(0)
@@ -54,21 +66,35 @@ class FramePipeline:
             _lib.dptr(img), _lib.dptr(self.d_labels.ptr), self.Y, self.X, ctypes.c_double(self.imgthresh),
             _lib.ptr(self.tseg), self.tseg.size, self.block, ctypes.byref(self.flags)))
 
-    def cell_tables(self, max_cells=None):
+    def segment_unet(self, predictor, atoh_channel=1, zo_channel=0):
+        """U1-U5 (pl.py:90-198) on the resident projection: (atoh, zo) planes transposed to (X, Y) as gui.py:2059-2061
+        hands them over; labels stay on the device (int32 (X, Y))."""
+        import torch
+        if getattr(self, "_proj_t", None) is None:
+            raise RuntimeError("FramePipeline(use_torch=True) is needed for the U-Net path")
+        self.sync()
+        img = torch.stack([self._proj_t[atoh_channel].T, self._proj_t[zo_channel].T])
+        lab, hc = predictor.predict(img, return_device=True)
+        self._unet_labels = lab
+        return lab, hc
+
+    def cell_tables(self, max_cells=None, labels_ptr=None, shape=None):
         """C1-C2 (ti.py:880-909, 1815-1842): per-cell reductions + neighbour pairs on the resident label map; the small
         per-cell arrays come back to the host (they are what a rank gathers for track stitching)."""
         P = self.Y * self.X
+        lab_ptr = self.d_labels.ptr if labels_ptr is None else labels_ptr
+        LY, LX = (self.Y, self.X) if shape is None else shape
         cap_cells = max_cells or max(1024, P // 64)
         if getattr(self, "_tables", None) is None or self._tables[0] < cap_cells:
             n = cap_cells
             self._tables = (n, _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 32), _lib.DeviceBuffer(n * 8),
                             _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 24), _lib.DeviceBuffer(16 * n * 8))
         n, d_area, d_bbox, d_sy, d_sx, d_pc, d_pairs = self._tables
-        _lib.check(self.lib.tip_regionprops_i32_dev(_lib.dptr(self.d_labels.ptr), None, self.Y, self.X, n,
+        _lib.check(self.lib.tip_regionprops_i32_dev(_lib.dptr(lab_ptr), None, LY, LX, n,
                                                     _lib.dptr(d_area.ptr), _lib.dptr(d_bbox.ptr), _lib.dptr(d_sy.ptr),
                                                     _lib.dptr(d_sx.ptr), _lib.dptr(d_pc.ptr), None))
         npairs = ctypes.c_int64(0)
-        _lib.check(self.lib.tip_neighbor_pairs_i32_dev(_lib.dptr(self.d_labels.ptr), self.Y, self.X,
+        _lib.check(self.lib.tip_neighbor_pairs_i32_dev(_lib.dptr(lab_ptr), LY, LX,
                                                        _lib.dptr(d_pairs.ptr), ctypes.c_int64(16 * n),
                                                        ctypes.byref(npairs)))
         area = d_area.download((n,), np.int64)

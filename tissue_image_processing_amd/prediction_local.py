@@ -228,7 +228,10 @@ class SegmentationPredictor:
         """pl.py:90-122: per-channel 1/99-percentile normalisation, (C,Y,X)->(1,X,Y,C), front-pad to powers of two.
         Returns a torch tensor laid out (1, C, X', Y') (the NCHW view of the reference's NHWC array) and npad."""
         torch = self.torch
-        t = torch.as_tensor(np.ascontiguousarray(image), device=self.device).to(torch.float64)
+        if isinstance(image, torch.Tensor):
+            t = image.to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(image), device=self.device).to(torch.float64)
         if t.dim() != 3:
             raise ValueError("image should be in axes order (C, Y, X)")
         C, Y, X = t.shape
@@ -252,16 +255,16 @@ class SegmentationPredictor:
         return padded, npad
 
     # -- U2-U5 --------------------------------------------------------------------------------------------
-    def predict(self, image, debug=False):
+    def predict(self, image, debug=False, return_device=False):
         torch = self.torch
         padded, npad = self.prepare_image(image)
         prob = self.model.forward(padded)                              # (1, 2, X', Y') float32
         unp = prob[:, :, npad[1][0]:, npad[2][0]:]
         p0 = unp[0, 0]
-        labels, hc = self.segment_probability(p0)
+        labels, hc = self.segment_probability(p0, return_device=return_device)
         return labels, hc
 
-    def segment_probability(self, p0, thr=0.1):
+    def segment_probability(self, p0, thr=0.1, return_device=False):
         """pl.py:167-194 on a device-resident probability map (torch tensor (X, Y)): threshold -> 5x5 closing ->
         7x7 erosion -> boundary -> watershed.  Returns (labels int32, HC float64) as numpy arrays."""
         torch = self.torch
@@ -287,4 +290,6 @@ class SegmentationPredictor:
         _lib.check(lib.tip_watershed_f64_dev(P(a), P(lab), Xn, Yn, 1, ctypes.byref(flags)))
         _lib.check(lib.tip_sync())
         self.last_flags = flags.value
+        if return_device:
+            return lab, hc
         return lab.cpu().numpy(), hc.cpu().numpy()
