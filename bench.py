@@ -32,6 +32,10 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
         "argmax_z": V * 4 + P * 16,
         "mask_ypass": P * 4 + V * 4,
         "xpass_wmax": V * 4 + C * V * 2 + C * P * 8,
+        # 2-D stages: watershed f64 -> i32 = P*8 + P*4 per frame; a launch of the tile kernel is one
+        # global iteration over the same frame, so the per-launch figure is the per-frame one
+        "ws_tiles": P * 12, "ws_tiles_wide": P * 12,
+        "regionprops": P * 4, "neighbor_pairs": P * 4, "local_threshold": 2 * P * 8,
     }
     return table.get(kernel)
 
@@ -167,7 +171,7 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            Ys, Xs = min(Y, 512), min(X, 512)
+            Ys, Xs = min(Y, 1024), min(X, 1024)
             dt = cpu_baseline((Ys, Xs), Z, workload)
             scale = (Y * X) / float(Ys * Xs)
             out["cpu_baseline"] = {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": 1, "kind": "port",
