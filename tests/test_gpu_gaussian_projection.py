@@ -142,3 +142,19 @@ def test_projection_full_size_properties(mods):
     proj2, zmap2 = sp.time_point_surface_projection(st2[None], "TCZYX", 0, airyscan=False, z_map=True)
     np.testing.assert_array_equal(zmap, zmap2)
     np.testing.assert_array_equal(proj[0], proj2[0])
+
+
+def test_projection_fast_path_equals_generic_path(mods, monkeypatch):
+    """Register-sliding / sparse-mask kernels are the same arithmetic as the generic kernels: bit-identical output."""
+    _, sp, _ = mods
+    from tissue_image_processing_amd import synthetic
+    for shape, seed in [((9, 200, 264), 1), ((5, 77, 136), 2), ((30, 128, 512), 3)]:
+        st = synthetic.make_stack(*shape, seed=seed)
+        st[1, :, :10, :] = 0
+        monkeypatch.delenv("TIP_PROJECT_GENERIC", raising=False)
+        p_fast, z_fast = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True, atoh_shift=-1)
+        monkeypatch.setenv("TIP_PROJECT_GENERIC", "1")
+        p_gen, z_gen = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True, atoh_shift=-1)
+        monkeypatch.delenv("TIP_PROJECT_GENERIC", raising=False)
+        np.testing.assert_array_equal(z_fast, z_gen)
+        np.testing.assert_array_equal(p_fast, p_gen)

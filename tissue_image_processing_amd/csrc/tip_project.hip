@@ -7,7 +7,8 @@
 //   P5  argmax over z, first maximum (sp.py:61)
 //   P6/P7 one-hot mask + Gaussian (1,2,2) (sp.py:62-71)             z pass = ZxZ table, y pass from the z-map,
 //   P8  per-channel max_z(image * mask) -> float64 (sp.py:72-81)    x pass fused with the weighted z-max
-#include "tip_corr.h"
+#include "tip_slide.h"
+#include <cstdlib>
 
 namespace tip {
 
@@ -216,6 +217,133 @@ __global__ void __launch_bounds__(256) k_xpass_wmax(const float *__restrict__ ym
         if (c < C && ((chan_mask >> c) & 1u)) proj[(long)c * P + (long)y * X + x] = (double)mx[c];
 }
 
+// ---- fast mask stage: the blurred one-hot mask is exactly zero more than 4 planes away from every chosen plane that
+// feeds it, and adding exact zeros changes nothing, so only the planes inside [zmin-4, zmax+4] of the 17-wide windows
+// are computed (same arithmetic, same order, bit-identical to the dense kernels above) -----------------------------------
+constexpr int MASK_R = 8, MASK_W = 2 * MASK_R + 1, MASK_ZR = 4;
+
+template <int SEG>
+__global__ void __launch_bounds__(256) k_mask_y_sparse(const float *__restrict__ table, const int32_t *__restrict__ zsel, int Zs,
+                                                       int Y, int X, Taps taps, float *__restrict__ out,
+                                                       int32_t *__restrict__ zrange)
+{
+    extern __shared__ float sT[];  // Zs*Zs: T[z*Zs + z0]
+    for (int i = threadIdx.x; i < Zs * Zs; i += blockDim.x) sT[i] = table[i];
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= X) return;
+    const int y0 = blockIdx.y * (SEG * MASK_W);
+    const long P = (long)Y * X;
+    int win[MASK_W];
+#pragma unroll
+    for (int i = 0; i < MASK_W; ++i) win[i] = zsel[(long)clampi(y0 - MASK_R + i, 0, Y - 1) * X + x];
+    for (int s = 0; s < SEG; ++s) {
+#pragma unroll
+        for (int o = 0; o < MASK_W; ++o) {
+            const int y = y0 + s * MASK_W + o;
+            if (y < Y) {
+                int zmin = win[0], zmax = win[0];
+#pragma unroll
+                for (int i = 1; i < MASK_W; ++i) { zmin = min(zmin, win[i]); zmax = max(zmax, win[i]); }
+                zrange[(long)y * X + x] = zmin | (zmax << 16);
+                const int za = max(zmin - MASK_ZR, 0), zb = min(zmax + MASK_ZR, Zs - 1);
+                float *dst = out + (long)y * X + x;
+                for (int z = 0; z < za; ++z) dst[(long)z * P] = 0.f;
+                for (int z = za; z <= zb; ++z) {
+                    const float *Tz = sT + z * Zs;
+                    double tmp = (double)Tz[win[(o + MASK_R) % MASK_W]] * taps.w[MASK_R];
+#pragma unroll
+                    for (int d = MASK_R; d >= 1; --d)
+                        tmp += ((double)Tz[win[(o + MASK_R - d) % MASK_W]] + (double)Tz[win[(o + MASK_R + d) % MASK_W]]) *
+                               taps.w[MASK_R - d];
+                    dst[(long)z * P] = (float)tmp;
+                }
+                for (int z = zb + 1; z < Zs; ++z) dst[(long)z * P] = 0.f;
+            }
+            win[o % MASK_W] = zsel[(long)clampi(y + MASK_R + 1, 0, Y - 1) * X + x];
+        }
+    }
+}
+
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restrict__ ymask, const int32_t *__restrict__ zrange,
+                                                           const uint16_t *__restrict__ img, int C, int Zfull, int zlo, int Zs,
+                                                           int Y, int X, int airy, unsigned chan_mask, Taps taps,
+                                                           double *__restrict__ proj)
+{
+    constexpr int N = 8 + 2 * MASK_R;  // 24 inputs for 8 outputs
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int y = blockIdx.y;
+    if (x0 >= X) return;
+    const long P = (long)Y * X;
+    const bool interior = x0 - MASK_R >= 0 && x0 + 8 + MASK_R <= X && (X & 3) == 0;
+    int zmin = 1 << 30, zmax = -1;
+    for (int i = 0; i < N; ++i) {
+        const int r = zrange[(long)y * X + clampi(x0 - MASK_R + i, 0, X - 1)];
+        zmin = min(zmin, r & 0xffff);
+        zmax = max(zmax, r >> 16);
+    }
+    const int za = max(zmin - MASK_ZR, 0), zb = min(zmax + MASK_ZR, Zs - 1);
+    float mx[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx[c][k] = 0.f;
+    for (int z = za; z <= zb; ++z) {
+        const float *row = ymask + (long)z * P + (long)y * X;
+        float v[N];
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < N / 4; ++i) {
+                const float4 f = *reinterpret_cast<const float4 *>(row + x0 - MASK_R + 4 * i);
+                v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = row[clampi(x0 - MASK_R + i, 0, X - 1)];
+        }
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double tmp = (double)v[k + MASK_R] * taps.w[MASK_R];
+#pragma unroll
+            for (int d = MASK_R; d >= 1; --d)
+                tmp += ((double)v[k + MASK_R - d] + (double)v[k + MASK_R + d]) * taps.w[MASK_R - d];
+            m[k] = (float)tmp;
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < C && ((chan_mask >> c) & 1u)) {
+                const uint16_t *ip = img + ((long)c * Zfull + zlo + z) * P + (long)y * X + x0;
+                unsigned short pix[8];
+                if (x0 + 8 <= X && (X & 7) == 0) {
+                    const uint4 u = *reinterpret_cast<const uint4 *>(ip);
+                    pix[0] = u.x & 0xffff; pix[1] = u.x >> 16; pix[2] = u.y & 0xffff; pix[3] = u.y >> 16;
+                    pix[4] = u.z & 0xffff; pix[5] = u.z >> 16; pix[6] = u.w & 0xffff; pix[7] = u.w >> 16;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pix[k] = x0 + k < X ? ip[k] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (x0 + k < X) {
+                        float val = (float)pix[k];
+                        if (airy) { val -= 10000.f; if (val < 0.f) val = 0.f; }
+                        const float pr = val * m[k];
+                        mx[c][k] = pr > mx[c][k] ? pr : mx[c][k];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C && ((chan_mask >> c) & 1u))
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (x0 + k < X) proj[(long)c * P + (long)y * X + x0 + k] = (double)mx[c][k];
+}
+
 static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
 {
     double buf[256];
@@ -253,6 +381,8 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     int32_t *zsel = ws.get<int32_t>(P), *zsel_a = ws.get<int32_t>(P);
     float *ident = ws.get<float>((size_t)Zs * Zs), *table = ws.get<float>((size_t)Zs * Zs);
     int *err = ws.get<int>(1);
+    int32_t *zrange = ws.get<int32_t>(P);
+    if (!zrange) return TIP_ERR_NOMEM;
     if (!A || !B || !hist || !clip || !zsel || !zsel_a || !ident || !table || !err) return TIP_ERR_NOMEM;
 
     const uint16_t *ref = czyx + ((long)ref_ch * Z + zlo) * P;
@@ -261,16 +391,26 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, ref, V, airyscan, hist);
     TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip);
 
-    // P3: (0.5, 1, 1)
-    {
+    const bool fast = (X % 4 == 0) && !getenv("TIP_PROJECT_GENERIC");
+    if (fast) {
+        // P3: (0.5, 1, 1) and P4's z pass with register-sliding kernels (each input loaded once per thread)
+        Src4U16Clip su{ref, airyscan, &clip->p95, &clip->has};
+        TIP_LAUNCH("zpass_u16clip_x4", (k_zpass_r2_x4<Src4U16Clip>), dim3(cdiv(P / 4, 256)), dim3(256), 0, su, A, Zs, P, k05);
+        TIP_LAUNCH("ypass_slide_r4", (k_ypass_slide<4, 4>), dim3(cdiv(X, 256), cdiv(Y, 36), Zs), dim3(256), 0, (const float *)A, B, Y,
+                   X, k1);
+        TIP_LAUNCH("xpass_slide_r4", (k_xpass_slide<4>), dim3(cdiv(cdiv(X, 8), 256), Y, Zs), dim3(256), 0, (const float *)B, A, Y, X,
+                   k1);
+        Src4F32 sf{A};
+        TIP_LAUNCH("zpass_f32_x4", (k_zpass_r2_x4<Src4F32>), dim3(cdiv(P / 4, 256)), dim3(256), 0, sf, B, Zs, P, k05);
+    } else {
         LoadU16Clip ld{ref, P, (long)X, airyscan, clip};
         dim3 grid(cdiv(X, 256), Y, Zs), block(256);
         TIP_LAUNCH("corr_z_u16clip", (k_corr_generic<float, 0, LoadU16Clip>), grid, block, 0, ld, A, Zs, Y, X, k05);
+        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 1, k1, 0))) return rc;
+        if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 2, k1, 0))) return rc;
+        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 0, k05, 0))) return rc;
     }
-    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 1, k1, 0))) return rc;
-    if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 2, k1, 0))) return rc;
-    // P4: (0.5, 30, 30)
-    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 0, k05, 0))) return rc;
+    // P4: (0.5, 30, 30) -- long-kernel passes
     if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
     if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
     // P5
@@ -285,11 +425,18 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         const int32_t *sel = pass == 0 ? zsel : zsel_a;
         unsigned cm = atoh_shift == 0 ? all : (pass == 0 ? (1u << ref_ch) : (all & ~(1u << ref_ch)));
         if (!cm) continue;
-        LoadMaskTable ld{table, sel, Zs, (long)X};
-        dim3 grid(cdiv(X, 256), Y, Zs), block(256);
-        TIP_LAUNCH("mask_ypass", (k_corr_generic<float, 1, LoadMaskTable>), grid, block, 0, ld, A, Zs, Y, X, k2);
-        TIP_LAUNCH("xpass_wmax", (k_xpass_wmax<8>), dim3(cdiv(X, 256), Y), dim3(256), 0, A, czyx, C, Z, zlo, Zs, Y, X,
-                   airyscan, cm, k2, proj);
+        if (fast && Zs <= 64 && (long)Zs * Y < 2147483647L) {
+            TIP_LAUNCH("mask_y_sparse", (k_mask_y_sparse<2>), dim3(cdiv(X, 256), cdiv(Y, 2 * MASK_W)), dim3(256),
+                       (size_t)Zs * Zs * sizeof(float), (const float *)table, sel, Zs, Y, X, k2, A, zrange);
+            TIP_LAUNCH("xpass_wmax_sparse", (k_xpass_wmax_sparse<8>), dim3(cdiv(cdiv(X, 8), 256), Y), dim3(256), 0, (const float *)A,
+                       (const int32_t *)zrange, czyx, C, Z, zlo, Zs, Y, X, airyscan, cm, k2, proj);
+        } else {
+            LoadMaskTable ld{table, sel, Zs, (long)X};
+            dim3 grid(cdiv(X, 256), Y, Zs), block(256);
+            TIP_LAUNCH("mask_ypass", (k_corr_generic<float, 1, LoadMaskTable>), grid, block, 0, ld, A, Zs, Y, X, k2);
+            TIP_LAUNCH("xpass_wmax", (k_xpass_wmax<8>), dim3(cdiv(X, 256), Y), dim3(256), 0, A, czyx, C, Z, zlo, Zs, Y, X,
+                       airyscan, cm, k2, proj);
+        }
     }
     if (min_z > 0 || atoh_shift > 0) {
         int h = 0;
