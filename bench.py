@@ -67,7 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

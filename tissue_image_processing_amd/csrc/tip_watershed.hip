@@ -254,6 +254,9 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool ce
     return d;
 }
 
+// One block = one 32x32 tile (+ halo) iterated to its local fixed point.  Work list: only undecided cells that touch a
+// labelled cell (the frontier) are evaluated each round; a cell that gets labelled wakes its undecided interior
+// neighbours.  Cheap rule while the tile progresses, pocket certificates for one round when it stalls.
 template <int WH, int WK>
 __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
@@ -265,8 +268,10 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     __shared__ int slab[WL * WL];
     __shared__ int sti[WL * WL];
     __shared__ int sgi[WL * WL];
+    __shared__ int sinl[WL * WL];
     __shared__ unsigned short svis[256 * WK];
-    __shared__ int s_any[2], s_und;
+    __shared__ unsigned short slist[2][WT * WT];
+    __shared__ int s_n[2], s_any, s_und, s_chg;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
     if (first == 2 && tile_und[tile] == 0) return;  // wide pass: every tile that still has undecided pixels
     if (!first) {
@@ -283,6 +288,7 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     for (int c = threadIdx.x; c < WL * WL; c += 256) {
         const int ly = c / WL, lx = c - ly * WL;
         const int gy = gy0 + ly, gx = gx0 + lx;
+        sinl[c] = 0;
         if (gy < 0 || gy >= Y || gx < 0 || gx >= X) {
             slab[c] = LINE_LAB; sv[c] = 0.0; sti[c] = 0; sgi[c] = -1;
         } else {
@@ -291,48 +297,74 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
             sv[c] = v[gi]; slab[c] = st_lab(s); sti[c] = st_tref(s); sgi[c] = gi;
         }
     }
-    if (threadIdx.x == 0) { s_any[0] = 0; s_any[1] = 0; s_und = 0; }
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; }
     __syncthreads();
     TileView tv{sv, slab, sti, sgi, v, svis + threadIdx.x * WK, WK, WL};
-    int cells[4];
-#pragma unroll
+    // initial frontier: undecided interior cells next to a labelled cell
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const int p = threadIdx.x + k * 256;
-        cells[k] = (p / WT + WH) * WL + (p % WT + WH);
+        const int c = (p / WT + WH) * WL + (p % WT + WH);
+        if (slab[c] == 0 && (slab[c - WL] > 0 || slab[c - 1] > 0 || slab[c + 1] > 0 || slab[c + WL] > 0)) {
+            sinl[c] = 1;
+            slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
+        }
     }
-    int my_changes = 0, my_evals = 0, my_rounds = 0;
+    __syncthreads();
+    int cur = 0, my_evals = 0, my_rounds = 0;
     bool certs = false;
     for (int round = 0; round < max_rounds; ++round) {
+        const int n = s_n[cur];
+        if (n == 0) break;
         my_rounds++;
+        int cc[4];
         Decision dec[4];
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            dec[k].lab = 0;
-            if (slab[cells[k]] == 0) {
-                my_evals++;
-                dec[k] = ws_decide(tv, cells[k], certs);
-                any |= dec[k].lab != 0;
-            }
+        int cnt = 0;
+#pragma unroll 1
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = slist[cur][i];
+            cc[cnt] = c;
+            dec[cnt].lab = 0; dec[cnt].ti = 0;
+            if (slab[c] == 0) { my_evals++; dec[cnt] = ws_decide(tv, c, certs); }
+            else cc[cnt] = -1;  // decided meanwhile (pushed by a neighbour in the round it was decided itself)
+            cnt++;
         }
         __syncthreads();  // every read of this round is done
-        if (threadIdx.x == 0) s_any[(round + 1) & 1] = 0;
-        if (any) s_any[round & 1] = 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (dec[k].lab != 0) {
-                slab[cells[k]] = dec[k].lab; sti[cells[k]] = dec[k].ti;
-                my_changes++;
-            }
+        if (threadIdx.x == 0) { s_n[cur ^ 1] = 0; s_any = 0; }
         __syncthreads();
-        if (s_any[round & 1]) { certs = false; continue; }
+#pragma unroll 1
+        for (int j = 0; j < cnt; ++j) {
+            const int c = cc[j];
+            if (c < 0) continue;
+            if (dec[j].lab == 0) {  // still waiting: stays on the frontier
+                slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
+                continue;
+            }
+            slab[c] = dec[j].lab; sti[c] = dec[j].ti; sinl[c] = 0;
+            s_any = 1;
+            atomicAdd(&s_chg, 1);
+            if (dec[j].lab > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+                    const int qy = q / WL, qx = q - qy * WL;
+                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && slab[q] == 0 && atomicExch(&sinl[q], 1) == 0)
+                        slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (s_any) { certs = false; continue; }
         if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
         certs = true;       // local stall: one round with pocket certificates
     }
+    __syncthreads();
     int und = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        const int c = cells[k];
+        const int p = threadIdx.x + k * 256;
+        const int c = (p / WT + WH) * WL + (p % WT + WH);
         const int gi = sgi[c];
         if (gi >= 0) {
             const int l = slab[c];
@@ -340,13 +372,12 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
             else if (st_lab(st[gi]) == 0) st[gi] = pack_st(l, sti[c]);
         }
     }
-    const int tot_changes = __syncthreads_count(my_changes > 0);
     if (und) atomicAdd(&s_und, und);
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_und[tile] = s_und;
-        changed_cur[tile] = tot_changes > 0;
-        if (tot_changes > 0) atomicAdd(&info->changed, tot_changes);
+        changed_cur[tile] = s_chg > 0;
+        if (s_chg > 0) atomicAdd(&info->changed, s_chg);
         if (s_und) atomicAdd(&info->undecided, s_und);
         atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
         atomicAdd(&info->dbg_tiles, 1ULL);
@@ -422,6 +453,138 @@ __global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long 
     if (s_lab != 0) st[i] = pack_st(conflict ? LINE_LAB : s_lab, i);
     else if (has_pull) st[i] = pack_st(pull_lab, pull_tr);
     info->changed = 1;
+}
+
+// ---- mode A endgame: what is still undecided when the tile launches stall are stuck pockets and the pixels that
+// wait for them.  Connected components of undecided pixels evolve independently (everything around them is final), so
+// each one is finished by ONE wave running the serial rule -- commit the component's smallest pop time, repeat -- on an
+// LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / global-minimum fallback.
+constexpr int END_CAP = 1024;
+
+struct SameU {
+    const unsigned long long *st;
+    __device__ __forceinline__ bool valid(int i) const { return st_lab(st[i]) == 0; }
+    __device__ __forceinline__ bool same(int, int) const { return true; }
+};
+
+__global__ void __launch_bounds__(256) k_end_count(const unsigned long long *__restrict__ st, const int *__restrict__ parent,
+                                                   int *__restrict__ cnt, int *__restrict__ isroot, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool u = st_lab(st[i]) == 0;
+    isroot[i] = (u && parent[i] == (int)i) ? 1 : 0;
+    if (u) atomicAdd(&cnt[parent[i]], 1);
+}
+
+__global__ void __launch_bounds__(256) k_end_scatter(const unsigned long long *__restrict__ st, const int *__restrict__ parent,
+                                                     const int *__restrict__ off, int *__restrict__ cursor,
+                                                     int *__restrict__ cells, int *__restrict__ slot,
+                                                     const int *__restrict__ isroot, const int *__restrict__ rootrank,
+                                                     int *__restrict__ roots, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (st_lab(st[i]) != 0) return;
+    const int r = parent[i];
+    const int k = atomicAdd(&cursor[r], 1);
+    cells[off[r] + k] = (int)i;
+    slot[i] = k;
+    if (isroot[i]) roots[rootrank[i]] = (int)i;
+}
+
+__global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
+                                                    const int *__restrict__ roots, const int *__restrict__ cnt,
+                                                    const int *__restrict__ off, const int *__restrict__ cells,
+                                                    const int *__restrict__ slot, int max_steps, WsInfo *info)
+{
+    __shared__ double cv[END_CAP];          // value of the cell
+    __shared__ int cgi[END_CAP];            // global index
+    __shared__ int clab[END_CAP], ctr[END_CAP];   // state: label / 0 / LINE and pop-time reference
+    // neighbour tables, [direction][cell] so that lanes walking consecutive cells hit consecutive banks
+    __shared__ int cnb[4][END_CAP];         // >= 0 local slot, -1 nothing (outside / line), -2 external labelled cell
+    __shared__ double ev[4][END_CAP];       // external labelled neighbour: pop-time value
+    __shared__ int etr[4][END_CAP], elab[4][END_CAP];
+    const int r = roots[blockIdx.x];
+    const int m = cnt[r];
+    if (m > END_CAP) { if (threadIdx.x == 0) atomicAdd(&info->undecided, m); return; }
+    const int base = off[r];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < m; k += 64) {
+        const int gi = cells[base + k];
+        const int y = gi / X, x = gi - y * X;
+        cv[k] = v[gi]; cgi[k] = gi; clab[k] = 0; ctr[k] = 0;
+        const int nb[4] = {y > 0 ? gi - X : -1, x > 0 ? gi - 1 : -1, x < X - 1 ? gi + 1 : -1, y < Y - 1 ? gi + X : -1};
+        for (int j = 0; j < 4; ++j) {
+            int code = -1;
+            if (nb[j] >= 0) {
+                const unsigned long long s = st[nb[j]];
+                const int l = st_lab(s);
+                if (l == 0) code = slot[nb[j]];
+                else if (l > 0) {
+                    const int tr = st_tref(s);
+                    code = -2; elab[j][k] = l; etr[j][k] = tr; ev[j][k] = v[tr];
+                }
+            }
+            cnb[j][k] = code;
+        }
+    }
+    __syncthreads();
+    int committed = 0;
+    // only the first max_steps commits are serial: that clears the stuck seeds; their dependents are ordinary pixels
+    // again and go back to the (parallel) tile rounds
+    for (int step = 0; step < max_steps; ++step) {
+        // every lane: best (smallest pop time) among its undecided cells that touch a labelled cell
+        double bv = 0.0; int bi = 0, bk = -1;
+        for (int k = lane; k < m; k += 64) {
+            if (clab[k] != 0) continue;
+            bool has = false; double tv = 0.0; int ti = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int code = cnb[j][k];
+                double qv; int qi;
+                if (code == -2) { qv = ev[j][k]; qi = etr[j][k]; }
+                else if (code >= 0 && clab[code] > 0) { const int tr = ctr[code]; qi = tr; qv = tr == cgi[code] ? cv[code] : v[tr]; }
+                else continue;
+                if (!has || qv < tv || (qv == tv && qi < ti)) { tv = qv; ti = qi; has = true; }
+            }
+            if (!has) continue;
+            // pop time = max(own key, earliest labelled neighbour)
+            double pv = cv[k]; int pi = cgi[k];
+            if (tv > pv || (tv == pv && ti > pi)) { pv = tv; pi = ti; }
+            if (bk < 0 || pv < bv || (pv == bv && (pi < bi || (pi == bi && cgi[k] < cgi[bk])))) { bv = pv; bi = pi; bk = k; }
+        }
+        // wave minimum over (bv, bi, cgi[bk])
+        int bg = bk >= 0 ? cgi[bk] : 0x7fffffff;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64), ok = __shfl_xor(bk, d, 64), og = __shfl_xor(bg, d, 64);
+            const bool take = ok >= 0 && (bk < 0 || ov < bv || (ov == bv && (oi < bi || (oi == bi && og < bg))));
+            if (take) { bv = ov; bi = oi; bk = ok; bg = og; }
+        }
+        if (bk < 0) break;  // nothing reachable is left (wave-uniform)
+        if (lane == 0) {
+            const int k = bk;
+            const double kv = cv[k]; const int ki = cgi[k];
+            int s_lab = 0, pull_lab = 0, pull_tr = 0; bool conflict = false, has_pull = false; double pt = 0.0; int pti = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int code = cnb[j][k];
+                double qv; int qi, ql;
+                if (code == -2) { qv = ev[j][k]; qi = etr[j][k]; ql = elab[j][k]; }
+                else if (code >= 0 && clab[code] > 0) { const int tr = ctr[code]; qi = tr; qv = tr == cgi[code] ? cv[code] : v[tr]; ql = clab[code]; }
+                else continue;
+                if (qv < kv || (qv == kv && qi < ki)) {
+                    if (s_lab == 0) s_lab = ql; else if (s_lab != ql) conflict = true;
+                } else if (!has_pull || qv < pt || (qv == pt && qi < pti)) { has_pull = true; pt = qv; pti = qi; pull_lab = ql; pull_tr = qi; }
+            }
+            if (s_lab != 0) { clab[k] = conflict ? LINE_LAB : s_lab; ctr[k] = ki; }
+            else { clab[k] = pull_lab; ctr[k] = pull_tr; }
+        }
+        committed++;
+        __syncthreads();
+    }
+    for (int k = lane; k < m; k += 64)
+        if (clab[k] != 0) st[cgi[k]] = pack_st(clab[k], ctr[k]);
+    if (lane == 0 && committed) atomicAdd(&info->changed, committed);
 }
 
 // ---- mode B: generation-synchronous BFS on a two-valued image --------------------------------------------------------
@@ -576,7 +739,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (!chg || !tile_und) return TIP_ERR_NOMEM;
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
         int iter = 0, fallbacks = 0;
-        bool wide = false;
+        bool wide = false, wide_after_endgame = false;
+        int endgames = 0;
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
@@ -601,6 +765,46 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 for (int v2 : hu) und_total += v2;
             }
             if (und_total == 0) break;
+            if (!wide_after_endgame) {
+                // serial rule on every small connected component of undecided pixels (one wave each, bounded steps)
+                SameU su{st};
+                if ((rc = uf_components(su, parent, Y, X))) return rc;
+                TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));      // cnt
+                TIP_LAUNCH("ws_end_count", k_end_count, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
+                           (const int *)parent, flag, isroot, n);
+                int *off = rank;                                            // exclusive scan of component sizes
+                if ((rc = exclusive_scan_i32(flag, off, n, nullptr))) return rc;
+                int *rootrank = ws.get<int>(n), *cursor = ws.get<int>(n), *cellsbuf = ws.get<int>(n), *slot = ws.get<int>(n),
+                    *roots = ws.get<int>(n), *ncomp_d = ws.get<int>(1);
+                if (!rootrank || !cursor || !cellsbuf || !slot || !roots || !ncomp_d) return TIP_ERR_NOMEM;
+                if ((rc = exclusive_scan_i32(isroot, rootrank, n, ncomp_d))) return rc;
+                TIP_HIP(hipMemsetAsync(cursor, 0, n * sizeof(int), s));
+                TIP_LAUNCH("ws_end_scatter", k_end_scatter, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
+                           (const int *)parent, (const int *)off, cursor, cellsbuf, slot, (const int *)isroot,
+                           (const int *)rootrank, roots, n);
+                int ncomp = 0;
+                TIP_HIP(hipMemcpyAsync(&ncomp, ncomp_d, sizeof(int), hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipStreamSynchronize(s));
+                TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
+                if (ncomp > 0)
+                    TIP_LAUNCH("ws_end_resolve", k_end_resolve, dim3(ncomp), dim3(64), 0, img, st, Y, X, (const int *)roots,
+                               (const int *)flag, (const int *)off, (const int *)cellsbuf, (const int *)slot, 48, info);
+                TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipStreamSynchronize(s));
+                if (getenv("TIP_WS_DEBUG"))
+                    fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d\n", ncomp, h.changed, h.undecided);
+                endgames++;
+                if (h.changed > 0) {             // seeds cleared: back to the tile rounds (every tile with undecided pixels)
+                    TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+                    continue;
+                }
+                if (h.undecided == 0) break;     // nothing reachable is left: the rest stays 0, as in the serial flood
+                // only oversize components remain: wide pass / global-minimum fallback machinery
+                wide_after_endgame = true;
+                TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+                wide = true;
+                continue;
+            }
             if (!wide) { wide = true; continue; }  // no progress with small pockets: one wide launch over every tile
             wide = false;
             // still nothing: pockets too large to certify locally -> commit the pixel with the globally smallest pop time
