@@ -125,7 +125,7 @@ def test_projection_errors(mods):
         sp.time_point_surface_projection(st2, "CZYX", 0, airyscan=False, atoh_shift=1)
 
 
-def test_projection_full_size_properties(mods):
+def test_projection_full_size_properties(mods, monkeypatch):
     """At BASELINE full size (2048x2048x30, C=2) the oracle is too slow; check size-independent properties:
     z-map range, projection >= 0, bounded by the per-pixel z-max of the stack, and invariance of the z-map
     under a global intensity scaling of the non-reference channel."""
@@ -137,6 +137,12 @@ def test_projection_full_size_properties(mods):
     assert zmap.min() >= 0 and zmap.max() < 30
     assert (proj >= 0).all()
     assert (proj <= st.max(axis=1).astype(np.float64) + 1e-9).all()
+    # certified (fast float32 score + exact fix-up) argmax == the all-exact float64 score path, at full size
+    monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
+    proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE")
+    assert int((zmap != zmap_e).sum()) == 0
+    np.testing.assert_array_equal(proj, proj_e)
     st2 = st.copy()
     st2[1] //= 2
     proj2, zmap2 = sp.time_point_surface_projection(st2[None], "TCZYX", 0, airyscan=False, z_map=True)
@@ -158,3 +164,24 @@ def test_projection_fast_path_equals_generic_path(mods, monkeypatch):
         monkeypatch.delenv("TIP_PROJECT_GENERIC", raising=False)
         np.testing.assert_array_equal(z_fast, z_gen)
         np.testing.assert_array_equal(p_fast, p_gen)
+
+
+def test_certified_argmax_equals_exact_score_path(mods, monkeypatch):
+    """The fast float32 score passes + certification + exact fix-up give the same z-map as the exact float64 passes,
+    including on data built to make neighbouring planes nearly tie."""
+    _, sp, _ = mods
+    from tissue_image_processing_amd import synthetic
+    rng = np.random.default_rng(9)
+    cases = [synthetic.make_stack(12, 300, 328, seed=11), synthetic.make_stack(30, 256, 256, seed=12)]
+    tie = np.zeros((2, 6, 160, 200), np.uint16)            # identical planes -> exact ties everywhere
+    tie[:, :, :, :] = rng.integers(50, 4000, (1, 1, 160, 200)).astype(np.uint16)
+    tie[0, 3, 80:, :] += 1                                  # and a one-count edge on plane 3
+    cases.append(tie)
+    for st in cases:
+        monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE", raising=False)
+        p_c, z_c = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+        monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
+        p_e, z_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+        monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE", raising=False)
+        assert int((z_c != z_e).sum()) == 0
+        np.testing.assert_array_equal(p_c, p_e)

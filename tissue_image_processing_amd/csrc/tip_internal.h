@@ -71,6 +71,10 @@ struct Taps {
     double w[256];
     int n;
 };
+struct TapsF {   // float32 copy for the certified fast score passes
+    float w[256];
+    int n;
+};
 
 int make_taps(Taps &t, const double *w, int n);  // validates odd + symmetric (scipy's symmetric branch)
 int libm_taps(double sigma, double truncate, double *w, int cap);

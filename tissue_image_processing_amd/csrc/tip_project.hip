@@ -344,6 +344,104 @@ __global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restri
                 if (x0 + k < X) proj[(long)c * P + (long)y * X + x0 + k] = (double)mx[c][k];
 }
 
+// ---- certified argmax --------------------------------------------------------------------------------------------------
+// The sigma-30 score is used for ONE thing: chosen_z = argmax_z(score) (sp.py:55-61).  So the score itself need not be
+// exact -- only the argmax must be.  The fast passes (k_corr_long_fast) give S~ with |S~ - S| <= EPS * S for the exact
+// float32 score S: each fast pass is within a = (1+u)^123 - 1 of the real-number sum and scipy's pass within 1.0001u of it
+// (u = 2^-24, all terms non-negative), two passes compose to 2a + 2.1u < 249u; EPS = 320u leaves > 25 % headroom.
+// A pixel is certified when its best fast score beats every other plane by more than both error bars; the few that
+// are not (top two planes closer than ~4e-5 relative: the lines where the surface crosses between planes) are
+// recomputed in exact scipy arithmetic from the z-passed volume, for the candidate planes only.
+#define CERT_EPS (320.0f * 5.9604644775390625e-8f)
+
+__global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict__ score, int Z, long P, int *__restrict__ best_z,
+                                                        int *__restrict__ unc_list, int *__restrict__ unc_count)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float b1 = score[p], b2 = -1.f;
+    int z1 = 0;
+    for (int z = 1; z < Z; ++z) {
+        const float s = score[(long)z * P + p];
+        if (s > b1) { b2 = b1; b1 = s; z1 = z; }
+        else if (s > b2) b2 = s;
+    }
+    best_z[p] = z1;
+    // b1 == 0: every plane is exactly zero in the fast pass, hence (no underflow for uint16-derived data) in the exact one
+    const bool certain = (b1 == 0.f) || (Z == 1) || (b1 * (1.f - CERT_EPS) > b2 * (1.f + CERT_EPS) + 1e-30f);
+    if (!certain) unc_list[atomicAdd(unc_count, 1)] = (int)p;
+}
+
+// one block per uncertified pixel: exact score of every candidate plane, then first-maximum argmax among them
+__global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restrict__ zvol, const float *__restrict__ score, int Z, int Y,
+                                                          int X, Taps taps, const int *__restrict__ unc_list,
+                                                          const int *__restrict__ unc_count, int *__restrict__ best_z)
+{
+    __shared__ float c[256];
+    __shared__ float sfast[64];
+    __shared__ float sexact[64];
+    __shared__ int s_z;
+    const int r = taps.n >> 1;  // 120
+    for (int u = blockIdx.x; u < *unc_count; u += gridDim.x) {
+        const int p = unc_list[u];
+        const int y = p / X, x = p - y * X;
+        const long P = (long)Y * X;
+        if (threadIdx.x < Z) sfast[threadIdx.x] = score[(long)threadIdx.x * P + p];
+        __syncthreads();
+        float smax = sfast[0];
+        for (int z = 1; z < Z; ++z) smax = fmaxf(smax, sfast[z]);
+        const float thr = smax * (1.f - CERT_EPS);
+        for (int z = 0; z < Z; ++z) {
+            const bool cand = sfast[z] * (1.f + CERT_EPS) + 1e-30f >= thr;  // block-uniform
+            if (!cand) { if (threadIdx.x == 0) sexact[z] = -1.f; continue; }
+            const float *vol = zvol + (long)z * P;
+            if (threadIdx.x < 2 * r + 1) {
+                const int xx = clampi(x + (int)threadIdx.x - r, 0, X - 1);
+                double tmp = (double)vol[(long)y * X + xx] * taps.w[r];
+                for (int d = r; d >= 1; --d)
+                    tmp += ((double)vol[(long)clampi(y - d, 0, Y - 1) * X + xx] + (double)vol[(long)clampi(y + d, 0, Y - 1) * X + xx]) *
+                           taps.w[r - d];
+                c[threadIdx.x] = (float)tmp;   // exact y pass, rounded to float32 like scipy's intermediate
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tmp = (double)c[r] * taps.w[r];
+                for (int d = r; d >= 1; --d) tmp += ((double)c[r - d] + (double)c[r + d]) * taps.w[r - d];
+                sexact[z] = (float)tmp;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float b = -2.f; int bz = 0;
+            for (int z = 0; z < Z; ++z)
+                if (sexact[z] > b) { b = sexact[z]; bz = z; }
+            best_z[p] = bz;
+        }
+        __syncthreads();
+    }
+}
+
+// writes the z-maps from the certified plane index (same outputs as k_argmax_z)
+__global__ void __launch_bounds__(256) k_emit_zmaps(const int *__restrict__ best_z, int Z, long P, int min_z, int atoh_shift,
+                                                    int32_t *__restrict__ zsel, int32_t *__restrict__ zsel_atoh,
+                                                    int64_t *__restrict__ zmap, int *__restrict__ err)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int cz = min_z + best_z[p];
+    if (zmap) zmap[p] = cz;
+    int ca = cz;
+    if (atoh_shift != 0) { ca = cz + atoh_shift; ca = ca < 0 ? 0 : (ca > Z ? Z : ca); }
+    if (cz >= Z || ca >= Z) {
+        atomicOr(err, 1);
+        zsel[p] = cz >= Z ? Z - 1 : cz;
+        zsel_atoh[p] = ca >= Z ? Z - 1 : ca;
+        return;
+    }
+    zsel[p] = cz;
+    zsel_atoh[p] = ca;
+}
+
 static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
 {
     double buf[256];
@@ -410,12 +508,45 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 2, k1, 0))) return rc;
         if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 0, k05, 0))) return rc;
     }
-    // P4: (0.5, 30, 30) -- long-kernel passes
-    if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
-    if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
-    // P5
-    TIP_LAUNCH("argmax_z", k_argmax_z, dim3(cdiv(P, 256)), dim3(256), 0, B, Zs, P, min_z, atoh_shift, zsel, zsel_a,
-               zmap, err);
+    // P4 + P5: (0.5, 30, 30) score and its argmax
+    const bool certified = fast && Zs <= 64 && !getenv("TIP_PROJECT_EXACT_SCORE");
+    if (certified) {
+        float *D = ws.get<float>(V);
+        int *bestz = ws.get<int>(P), *unc = ws.get<int>(P), *uncn = ws.get<int>(1);
+        if (!D || !bestz || !unc || !uncn) return TIP_ERR_NOMEM;
+        TapsF f30;
+        f30.n = k30.n;
+        for (int i = 0; i < 256; ++i) f30.w[i] = (float)k30.w[i];
+        const int r = k30.n >> 1;
+        {   // fast y pass B -> A, fast x pass A -> D   (B, the exact z-passed volume, is kept for the exact fix-up)
+            size_t lds = (size_t)(256 + 2 * r) * 64 * sizeof(float);
+            auto ky = k_corr_long_fast<1, 256, 16>;
+            TIP_HIP(hipFuncSetAttribute((const void *)ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TIP_LAUNCH("score_fast_y", ky, dim3(cdiv(X, 64), cdiv(Y, 256), Zs), dim3(1024), lds, (const float *)B, A, Zs, Y, X, f30);
+            lds = (size_t)(256 + 2 * r) * 65 * sizeof(float);
+            auto kx = k_corr_long_fast<2, 256, 16>;
+            TIP_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TIP_LAUNCH("score_fast_x", kx, dim3(cdiv(Y, 64), cdiv(X, 256), Zs), dim3(1024), lds, (const float *)A, D, Zs, Y, X, f30);
+        }
+        TIP_HIP(hipMemsetAsync(uncn, 0, sizeof(int), c.stream));
+        TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(P, 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
+        TIP_LAUNCH("argmax_exact_fix", k_argmax_exact_fix, dim3(2048), dim3(256), 0, (const float *)B, (const float *)D, Zs, Y, X,
+                   k30, (const int *)unc, (const int *)uncn, bestz);
+        TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
+                   zsel_a, zmap, err);
+        if (getenv("TIP_PROJECT_DEBUG")) {
+            int hn = 0;
+            TIP_HIP(hipMemcpyAsync(&hn, uncn, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TIP_HIP(hipStreamSynchronize(c.stream));
+            fprintf(stderr, "certified argmax: %d of %ld pixels recomputed exactly\n", hn, P);
+        }
+    } else {
+        if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
+        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
+        // P5
+        TIP_LAUNCH("argmax_z", k_argmax_z, dim3(cdiv(P, 256)), dim3(256), 0, B, Zs, P, min_z, atoh_shift, zsel, zsel_a, zmap,
+                   err);
+    }
     // P6/P7 z pass as a Zs x Zs table (sigma 1 -> 9 taps), built with the same correlate kernel
     TIP_LAUNCH("identity", k_identity, dim3(cdiv((long)Zs * Zs, 256)), dim3(256), 0, ident, Zs);
     if ((rc = correlate1d_dev(ident, table, 0, Zs, Zs, 1, 0, k1, 1))) return rc;
