@@ -29,6 +29,9 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
         "corr_z_u16clip": V * 2 + V * 4,
         "corr_generic_z": 2 * V * 4, "corr_generic_y": 2 * V * 4, "corr_generic_x": 2 * V * 4,
         "corr_long_y": 2 * V * 4, "corr_long_x": 2 * V * 4,
+        "score_fast_y": 2 * V * 4, "score_fast_x": 2 * V * 4,
+        "zpass_u16clip_x4": V * 2 + V * 4, "zpass_f32_x4": 2 * V * 4, "ypass_slide_r4": 2 * V * 4, "xpass_slide_r4": 2 * V * 4,
+        "argmax_certify": V * 4 + P * 4, "mask_y_sparse": P * 4 + V * 4, "xpass_wmax_sparse": V * 4 + C * V * 2 + C * P * 8,
         "argmax_z": V * 4 + P * 16,
         "mask_ypass": P * 4 + V * 4,
         "xpass_wmax": V * 4 + C * V * 2 + C * P * 8,
@@ -36,8 +39,31 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
         # global iteration over the same frame, so the per-launch figure is the per-frame one
         "ws_tiles": P * 12, "ws_tiles_wide": P * 12,
         "regionprops": P * 4, "neighbor_pairs": P * 4, "local_threshold": 2 * P * 8,
+        "corr_generic_y_f64": 2 * P * 8, "corr_generic_x_f64": 2 * P * 8,
     }
     return table.get(kernel)
+
+
+PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r01c_pmc_traffic.json
+    "ws_tiles": "k_ws_tiles<3, 6>", "score_fast_y": "k_corr_long_fast<1", "score_fast_x": "k_corr_long_fast<2",
+    "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
+    "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",
+    "regionprops": "k_regionprops", "hist_u16": "k_hist_u16", "mask_y_sparse": "k_mask_y_sparse",
+    "xpass_wmax_sparse": "k_xpass_wmax_sparse", "argmax_certify": "k_argmax_certify",
+}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
+    key = PMC_NAMES.get(kernel)
+    if not key or not os.path.exists(path):
+        return None
+    for name, rec in json.load(open(path)).items():
+        if key in name:
+            return (rec["fetch_MB_per_call_x2corrected"] + rec["write_MB_per_call"]) * 1e6
+    return None
 
 
 def algorithmic_dp_ops(kernel, Z, Y, X):
@@ -146,6 +172,7 @@ def main():
         roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "avg_launch_ms": ms / cnt, "launches": cnt,
                 "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
+        roof["traffic"] = pmc_traffic(name)
         if ab:
             roof["achieved"] = ab / avg_s / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -157,7 +184,14 @@ def main():
             roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
                                  "frac": tf / (FP64_VALU_PEAK_TF / 2),
                                  "note": "separately rounded mul/add: one lane-op per instruction, peak = FMA peak / 2"}
-        kernels = {k: {"n": v[0], "ms_total": round(v[1], 4)} for k, v in rep.items()}
+        kernels = {}
+        for k, v in rep.items():
+            kernels[k] = {"n": v[0], "ms_total": round(v[1], 4)}
+            kb = algorithmic_bytes(k, C, Z, Y, X)
+            if kb:
+                gbs = kb / (v[1] / v[0] / 1e3) / 1e9
+                kernels[k]["hbm_GBps"] = round(gbs, 1)
+                kernels[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
         out = {
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

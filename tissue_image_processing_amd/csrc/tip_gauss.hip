@@ -12,9 +12,10 @@ static int corr_generic(const T *in, T *out, int Z, int Y, int X, int axis, cons
 {
     LoadPlain<T> ld{in, (long)Y * X, (long)X};
     dim3 grid(cdiv(X, 256), Y, Z), block(256);
-    if (axis == 0) TIP_LAUNCH("corr_generic_z", (k_corr_generic<T, 0, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
-    else if (axis == 1) TIP_LAUNCH("corr_generic_y", (k_corr_generic<T, 1, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
-    else TIP_LAUNCH("corr_generic_x", (k_corr_generic<T, 2, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
+    const bool f64 = sizeof(T) == 8;
+    if (axis == 0) TIP_LAUNCH(f64 ? "corr_generic_z_f64" : "corr_generic_z", (k_corr_generic<T, 0, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
+    else if (axis == 1) TIP_LAUNCH(f64 ? "corr_generic_y_f64" : "corr_generic_y", (k_corr_generic<T, 1, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
+    else TIP_LAUNCH(f64 ? "corr_generic_x_f64" : "corr_generic_x", (k_corr_generic<T, 2, LoadPlain<T>>), grid, block, 0, ld, out, Z, Y, X, t);
     return TIP_OK;
 }
 
