@@ -137,12 +137,12 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 }
 
 // ---- mode A: tile-local rounds ------------------------------------------------------------------------------------------
-constexpr int WT = 32;           // tile interior
+// tile interior / threads per block are template parameters (32x32 / 256 measured best; 64x64 / 1024 was 18 % slower)
 // Two launch flavours: the everyday one certifies pockets of up to 6 cells inside a 3-pixel halo; when a whole
 // launch makes no progress the wide one (12-pixel halo, 48-cell pockets: stuck pockets are thin staircases up to
 // ~10 px long on smooth landscapes) is tried before the global-minimum fallback.
-constexpr int WH_FAST = 3, WK_FAST = 6;
-constexpr int WH_WIDE = 12, WK_WIDE = 48;
+constexpr int WT_FAST = 32, WTH_FAST = 256, WH_FAST = 3, WK_FAST = 6;
+constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 constexpr int LINE_LAB = -1;
 
 struct T2 { double v; int i; };
@@ -257,8 +257,8 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool ce
 // One block = one 32x32 tile (+ halo) iterated to its local fixed point.  Work list: only undecided cells that touch a
 // labelled cell (the frontier) are evaluated each round; a cell that gets labelled wakes its undecided interior
 // neighbours.  Cheap rule while the tile progresses, pocket certificates for one round when it stalls.
-template <int WH, int WK>
-__global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
+template <int WT, int WS_THREADS, int WH, int WK>
+__global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
                                                   unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
                                                   int first, int max_rounds, WsInfo *info)
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     __shared__ int sti[WL * WL];
     __shared__ int sgi[WL * WL];
     __shared__ int sinl[WL * WL];
-    __shared__ unsigned short svis[256 * WK];
+    __shared__ unsigned short svis[WS_THREADS * WK];
     __shared__ unsigned short slist[2][WT * WT];
     __shared__ int s_n[2], s_any, s_und, s_chg;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
         if (!act) return;
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
-    for (int c = threadIdx.x; c < WL * WL; c += 256) {
+    for (int c = threadIdx.x; c < WL * WL; c += WS_THREADS) {
         const int ly = c / WL, lx = c - ly * WL;
         const int gy = gy0 + ly, gx = gx0 + lx;
         sinl[c] = 0;
@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     TileView tv{sv, slab, sti, sgi, v, svis + threadIdx.x * WK, WK, WL};
     // initial frontier: undecided interior cells next to a labelled cell
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        const int p = threadIdx.x + k * 256;
+    for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
+        const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
         if (slab[c] == 0 && (slab[c - WL] > 0 || slab[c - 1] > 0 || slab[c + 1] > 0 || slab[c + WL] > 0)) {
             sinl[c] = 1;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
         Decision dec[4];
         int cnt = 0;
 #pragma unroll 1
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += WS_THREADS) {
             const int c = slist[cur][i];
             cc[cnt] = c;
             dec[cnt].lab = 0; dec[cnt].ti = 0;
@@ -362,8 +362,8 @@ __global__ void __launch_bounds__(256) k_ws_tiles(const double *__restrict__ v, 
     __syncthreads();
     int und = 0;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        const int p = threadIdx.x + k * 256;
+    for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
+        const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
         const int gi = sgi[c];
         if (gi >= 0) {
@@ -733,7 +733,11 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                        (const unsigned char *)fate, n, gen);
         }
     } else if (h.n_markers > 0) {
-        const int tilesX = cdiv(X, WT), tilesY = cdiv(Y, WT), ntiles = tilesX * tilesY;
+        const int tilesX = cdiv(X, WT_FAST), tilesY = cdiv(Y, WT_FAST), ntiles = tilesX * tilesY;
+        const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
+        unsigned char *wchg = ws.get<unsigned char>((size_t)2 * wntiles);
+        int *wtile_und = ws.get<int>(wntiles);
+        if (!wchg || !wtile_und) return TIP_ERR_NOMEM;
         unsigned char *chg = ws.get<unsigned char>((size_t)2 * ntiles);
         int *tile_und = ws.get<int>(ntiles);
         if (!chg || !tile_und) return TIP_ERR_NOMEM;
@@ -746,11 +750,14 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
             TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
             if (!wide)
-                TIP_LAUNCH("ws_tiles", (k_ws_tiles<WH_FAST, WK_FAST>), dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX, tilesY,
-                           (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+                TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y, X,
+                           tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
             else
-                TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WH_WIDE, WK_WIDE>), dim3(ntiles), dim3(256), 0, img, st, Y, X, tilesX,
-                           tilesY, (const unsigned char *)prev, cur, tile_und, 2, 4096, info);
+            {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
+                TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img, st, Y,
+                           X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, 1, 4096, info);
+                TIP_HIP(hipMemsetAsync(cur, 1, ntiles, s));
+            }
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
             if (getenv("TIP_WS_DEBUG"))
@@ -819,7 +826,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // wake the tile of the committed pixel (its 3x3 neighbourhood follows through the activity rule)
             {
                 const int pi = (int)(unsigned)(h.fb_k & 0xffffffffULL);
-                const int t = (pi / X / WT) * tilesX + (pi % X) / WT;
+                const int t = (pi / X / WT_FAST) * tilesX + (pi % X) / WT_FAST;
                 TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles + t, 1, 1, s));
             }
         }
