@@ -1,0 +1,126 @@
+"""GPU: ragged / degenerate shapes and error paths, against the oracle."""
+import numpy as np
+import pytest
+
+from gpu_util import taps_patch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def env(monkeypatch, golden_taps, oracle_with_golden_taps):
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    from tissue_image_processing_amd import surface_projection as sp
+    from tissue_image_processing_amd import _segmentation as seg
+    taps_patch(monkeypatch, golden_taps)
+    return bim, sp, seg, oracle_with_golden_taps
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 33, 47), (2, 1, 40, 64), (1, 7, 64, 36), (3, 6, 1, 128), (2, 4, 130, 1),
+                                   (2, 9, 96, 132)])
+def test_projection_ragged_shapes(env, shape):
+    """X not a multiple of 4 takes the generic kernels, Z = 1, single rows / columns, one channel."""
+    _, sp, _, orc = env
+    rng = np.random.default_rng(sum(shape))
+    st = rng.integers(0, 4000, shape).astype(np.uint16)
+    st[:, :, : shape[2] // 2, :] //= 3
+    p_ref, z_ref = orc.time_point_surface_projection(st.copy(), "CZYX", 0, airyscan=False, z_map=True)
+    p, z = sp.time_point_surface_projection(st.copy(), "CZYX", 0, airyscan=False, z_map=True)
+    np.testing.assert_array_equal(z, z_ref)
+    np.testing.assert_array_equal(p, p_ref)
+
+
+def test_projection_airyscan_clamps_and_saturates(env):
+    _, sp, _, orc = env
+    rng = np.random.default_rng(3)
+    st = rng.integers(9000, 12000, (2, 6, 40, 48)).astype(np.uint16)
+    st[0, 2, 5:9, 5:9] = 65535
+    p_ref, z_ref = orc.time_point_surface_projection(st.copy(), "CZYX", 1, airyscan=True, z_map=True)
+    p, z = sp.time_point_surface_projection(st.copy(), "CZYX", 1, airyscan=True, z_map=True)
+    np.testing.assert_array_equal(z, z_ref)
+    np.testing.assert_array_equal(p, p_ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 50), (50, 1), (33, 70), (3, 3), (64, 64), (65, 97)])
+def test_watershed_ragged_shapes(env, shape):
+    _, _, seg, orc = env
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = rng.random(shape)
+    if min(shape) > 8:
+        img = orc.blur_image(img, 1.5)
+    out = seg.watershed(img)
+    np.testing.assert_array_equal(out, orc.watershed(img))
+
+
+def test_watershed_plateau_minima_and_zero_background(env):
+    """Exact-zero plateaus (thresholded background) are marker plateaus; bit-exact like any tie-free flood."""
+    bim, _, seg, orc = env
+    rng = np.random.default_rng(17)
+    img = orc.blur_image(rng.random((120, 150)), 2.0)
+    img[img < 0.47] = 0.0
+    img = orc.blur_image(img, 1.0)
+    img[20:40, 30:80] = 0.0
+    out, flags = seg.watershed(img, return_flags=True)
+    ref = orc.watershed(img)
+    assert int((out != ref).sum()) == 0, flags
+
+
+def test_label_edge_cases(env):
+    _, _, seg, orc = env
+    for a in [np.zeros((5, 7), np.int32), np.ones((4, 4), np.int32), np.arange(12, dtype=np.int32).reshape(3, 4) % 2,
+              np.ones((1, 9), np.int32), np.ones((9, 1), np.int32)]:
+        out, n = seg.label(a, background=0, return_num=True, connectivity=1)
+        ref, n_ref = orc.label4(a, 0)
+        np.testing.assert_array_equal(out, ref)
+        assert n == n_ref
+
+
+def test_cell_tables_with_gaps_in_labels(env):
+    """Label ids that are absent (area 0 rows) keep zero rows, like regionprops_table + make_df in the reference."""
+    _, _, seg, orc = env
+    lab = np.zeros((40, 50), np.int32)
+    lab[2:10, 3:12] = 1
+    lab[15:30, 20:45] = 4        # ids 2, 3 absent
+    lab[33:38, 5:9] = 6          # id 5 absent
+    rp = seg.regionprops_arrays(lab)
+    ref = orc.regionprops(lab)
+    np.testing.assert_array_equal(rp["area"], ref["area"])
+    np.testing.assert_array_equal(rp["bbox"][ref["area"] > 0], ref["bbox"][ref["area"] > 0])
+    np.testing.assert_allclose(rp["perimeter"], ref["perimeter"], rtol=1e-13)
+    np.testing.assert_array_equal(seg.neighbor_pairs(lab), orc.neighbor_pairs(lab))
+
+
+def test_argument_errors(env):
+    bim, sp, seg, _ = env
+    with pytest.raises(TypeError):
+        bim.blur_image(np.zeros((4, 4), np.int32), 1.0)
+    with pytest.raises(ValueError):
+        bim.blur_image(np.zeros((2, 2, 2, 2), np.float32), 1.0)
+    with pytest.raises(TypeError):
+        bim.watershed_segmentation(np.zeros((8, 8), np.uint8), 0.03, 3, 3)
+    with pytest.raises(ValueError):
+        seg.watershed(np.zeros((2, 3, 4)))
+    with pytest.raises(TypeError):
+        sp.time_point_surface_projection(np.zeros((2, 3, 8, 8), np.float64) - 1.0, "CZYX", 0, airyscan=False)
+
+
+def test_thread_reentrancy(env):
+    """Two Python threads (as the reference's Qt workers) call the library concurrently; results stay bit-exact."""
+    import threading
+    bim, _, _, orc = env
+    rng = np.random.default_rng(5)
+    vols = [(rng.random((4, 90, 110)) * 1000).astype(np.float32) for _ in range(4)]
+    refs = [orc.blur_image(v, (0.5, 2, 2)) for v in vols]
+    outs = [None] * 4
+
+    def work(i):
+        from tissue_image_processing_amd import _lib
+        _lib.init(0)
+        for _ in range(5):
+            outs[i] = bim.blur_image(vols[i], (0.5, 2, 2))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for o, r in zip(outs, refs):
+        np.testing.assert_array_equal(o, r)
