@@ -431,3 +431,44 @@ def closing_tail(p0, thr=0.1):
     bound = e - hc
     boundary = dilation(bound, 5)
     return watershed(boundary, watershed_line=True), hc, boundary, e
+
+
+# ----------------------------------------------------------------------------- drift (ti.py:1982-2035, bim.py:522-536)
+def phase_cross_correlation(reference_image, moving_image, upsample_factor=1):
+    """skimage.registration.phase_cross_correlation (0.18.3, space='real', no normalisation) restated with numpy.fft:
+    whole-pixel peak of ifft2(F1 * conj(F2)), then the matrix-multiply upsampled DFT in a 1.5-pixel neighbourhood
+    (skimage/registration/_phase_cross_correlation.py:11-76, 196-262).  Returns the shift vector only."""
+    a = np.asarray(reference_image, dtype=np.float64)
+    b = np.asarray(moving_image, dtype=np.float64)
+    src, tgt = np.fft.fft2(a), np.fft.fft2(b)
+    shape = src.shape
+    prod = src * tgt.conj()
+    cc = np.fft.ifft2(prod)
+    maxima = np.unravel_index(np.argmax(np.abs(cc)), cc.shape)
+    mid = np.array([np.fix(s / 2) for s in shape])
+    shifts = np.stack(maxima).astype(np.float64)
+    shifts[shifts > mid] -= np.array(shape)[shifts > mid]
+    if upsample_factor > 1:
+        shifts = np.round(shifts * upsample_factor) / upsample_factor
+        region = int(np.ceil(upsample_factor * 1.5))
+        dftshift = np.fix(region / 2.0)
+        uf = float(upsample_factor)
+        offs = dftshift - shifts * uf
+        data = prod.conj()
+        for (n_items, ax_off) in list(zip(shape, offs))[::-1]:
+            kernel = (np.arange(region) - ax_off)[:, None] * np.fft.fftfreq(n_items, uf)
+            kernel = np.exp(-1j * 2 * np.pi * kernel)
+            data = np.tensordot(kernel, data, axes=(1, -1))
+        cc2 = data.conj()
+        mx = np.unravel_index(np.argmax(np.abs(cc2)), cc2.shape)
+        shifts = shifts + (np.stack(mx).astype(np.float64) - dftshift) / uf
+    for d in range(2):
+        if shape[d] == 1:
+            shifts[d] = 0
+    return shifts
+
+
+def update_drift(previous_img, current_img):
+    """Tissue.update_drift without stage locations (ti.py:1982-2035): returns (shift_y, shift_x) = (refined[-1], refined[-2])."""
+    r = phase_cross_correlation(previous_img, current_img, upsample_factor=100)
+    return r[-1], r[-2]

@@ -196,3 +196,15 @@ def test_tracking(golden):
     ids = orc.track_simple(list(labs), tables, drifts)
     for f in range(labs.shape[0]):
         np.testing.assert_array_equal(ids[f], g["ids_%d" % f])
+
+
+def test_drift(golden):
+    g = golden("drift")
+    for tag in "abc":
+        imgs = g[tag + "_images"]
+        sy, sx = orc.update_drift(imgs[0], imgs[1])
+        np.testing.assert_array_equal(np.array([sy, sx]), g[tag + "_drift"])
+        np.testing.assert_array_equal(orc.phase_cross_correlation(imgs[0], imgs[1], 100), g[tag + "_calc"])
+        np.testing.assert_array_equal(orc.phase_cross_correlation(imgs[0], imgs[1], 1), g[tag + "_calc_whole"])
+        np.testing.assert_array_equal(orc.phase_cross_correlation(g[tag + "_prev_f64"], g[tag + "_cur_f64"], 100),
+                                      g[tag + "_calc_f64"])

@@ -108,3 +108,13 @@ def watershed_segmentation(image, imgthresh, stdeviation, blocksize):
     """
     from . import _segmentation
     return _segmentation.watershed_segmentation(image, imgthresh, stdeviation, blocksize)
+
+
+def calculate_drift(first_image, second_image, sub_pixel_precision=True):
+    """bim.py:522-536: global 2-D drift between two frames by phase cross-correlation (shift[-2:])."""
+    from ._registration import phase_cross_correlation
+    if sub_pixel_precision:
+        shift, error, diffphase = phase_cross_correlation(first_image, second_image, upsample_factor=100)
+    else:
+        shift, error, diffphase = phase_cross_correlation(first_image, second_image)
+    return shift[-2:]

@@ -341,12 +341,37 @@ class TissueHipMixin(object):
             yield frame
         return 0
 
+    @staticmethod
+    def calculate_refine_drift(previous_image, current_image, course_shift_x, course_shift_y):
+        """ti.py:1941-1980: crop the overlap given by the floored coarse shift, refine by phase cross-correlation."""
+        from ._registration import phase_cross_correlation
+        rx, ry = int(np.floor(course_shift_x)), int(np.floor(course_shift_y))
+        sl = lambda r: (slice(r, None), slice(None, -r)) if r > 0 else ((slice(None, r), slice(-r, None)) if r < 0 else
+                                                                        (slice(None), slice(None)))
+        (p0, c0), (p1, c1) = sl(rx), sl(ry)
+        previous_img = previous_image[p0, p1]
+        current_img = current_image[c0, c1]
+        refined_shift, _, _ = phase_cross_correlation(previous_img, current_img, upsample_factor=100)
+        return rx + refined_shift[-2], ry + refined_shift[-1]
+
     def update_drift(self, frame, previous_frame, images=None, image_in_memory=False):
-        """ti.py:1982-2035 without the FFT refinement (phase_cross_correlation is SURVEY.md 8f rank 2): the stage
-        shift (zero when no stage table is loaded) is stored and returned."""
+        """ti.py:1982-2035: stage shift (when a stage table is loaded) + phase-correlation refinement of the overlap.
+        x/y are swapped between the stage table and the image, exactly as upstream: returns (shift_y, shift_x)."""
+        stage = getattr(self, "stage_locations", None)
+        if stage is not None:
+            shift = (stage.loc[frame - 1, ["z", "y", "x"]].to_numpy() - stage.loc[previous_frame - 1, ["z", "y", "x"]].to_numpy()) / \
+                stage.loc[frame - 1, ["physical_size_z", "physical_size_y", "physical_size_x"]].to_numpy()
+        else:
+            shift = (0, 0)
+        shift_x = shift[-2]
+        shift_y = shift[-1]
         if images is not None:
-            raise NotImplementedError("phase-correlation drift refinement is out of scope this round (SURVEY.md 8f)")
-        shift_y, shift_x = 0, 0
+            previous_image = images[previous_frame - 1]
+            current_image = images[frame - 1]
+            if not image_in_memory:
+                previous_image = previous_image.compute()
+                current_image = current_image.compute()
+            shift_x, shift_y = self.calculate_refine_drift(np.asarray(previous_image), np.asarray(current_image), shift_x, shift_y)
         self.drifts[frame - 1, 0] = shift_y
         self.drifts[frame - 1, 1] = shift_x
         return shift_y, shift_x

@@ -370,6 +370,34 @@ def gold_weights():
     save("weights", **out)
 
 
+def gold_drift():
+    """T2: Tissue.update_drift / bim.calculate_drift (phase_cross_correlation, upsample_factor=100) on shifted frames."""
+    tmp = tempfile.mkdtemp(prefix="tipgold_")
+    rng = np.random.default_rng(81)
+    out = {}
+    for tag, (ny, nx), (dy, dx) in [("a", (128, 128), (2.37, -1.42)), ("b", (64, 256), (-3.08, 5.61)),
+                                      ("c", (256, 128), (0.0, 0.26))]:
+        base = ndi.gaussian_filter(rng.random((ny + 40, nx + 40)), 2.0)
+        fine = ndi.zoom(base, 1.0, order=1)
+        prev = fine[20:20 + ny, 20:20 + nx]
+        cur = ndi.shift(fine, (-dy, -dx), order=3, mode="reflect")[20:20 + ny, 20:20 + nx]
+        prev16 = np.round(prev * 40000).astype(np.uint16)
+        cur16 = np.round(cur * 40000 + rng.normal(0, 30, cur.shape)).clip(0, 65535).astype(np.uint16)
+        imgs = np.stack([prev16, cur16])
+        t = ti.Tissue(2, os.path.join(tmp, "movie_d" + tag), ["zo"])
+        sy, sx = t.update_drift(2, 1, images=imgs, image_in_memory=True)
+        out[tag + "_images"] = imgs
+        out[tag + "_drift"] = np.array([sy, sx])
+        out[tag + "_drifts_row"] = t.drifts[1].copy()
+        out[tag + "_calc"] = np.asarray(bim.calculate_drift(prev16, cur16))
+        out[tag + "_calc_whole"] = np.asarray(bim.calculate_drift(prev16, cur16, sub_pixel_precision=False))
+        f64 = bim.calculate_drift(prev.astype(np.float64), cur.astype(np.float64))
+        out[tag + "_calc_f64"] = np.asarray(f64)
+        out[tag + "_prev_f64"] = prev.astype(np.float64)
+        out[tag + "_cur_f64"] = cur.astype(np.float64)
+    save("drift", **out)
+
+
 def gold_percentile():
     rng = np.random.default_rng(71)
     a = rng.integers(0, 5000, 100003).astype(np.float32)
@@ -393,4 +421,5 @@ if __name__ == "__main__":
     gold_celltypes()
     gold_unet_tail()
     gold_tracking()
+    gold_drift()
     print("done")
