@@ -137,11 +137,13 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 }
 
 // ---- mode A: tile-local rounds ------------------------------------------------------------------------------------------
-// tile interior / threads per block are template parameters (32x32 / 256 measured best; 64x64 / 1024 was 18 % slower)
+// tile interior / threads per block are template parameters: 16x16 tiles with one wave each measured best (4.5 ms per
+// 2048^2 frame; 32x32 / 256 threads 5.0 ms; 64x64 / 1024 threads 5.9 ms): the rounds are latency bound, so what counts
+// is how many tiles a CU keeps in flight (LDS per tile)
 // Two launch flavours: the everyday one certifies pockets of up to 6 cells inside a 3-pixel halo; when a whole
 // launch makes no progress the wide one (12-pixel halo, 48-cell pockets: stuck pockets are thin staircases up to
 // ~10 px long on smooth landscapes) is tried before the global-minimum fallback.
-constexpr int WT_FAST = 32, WTH_FAST = 256, WH_FAST = 3, WK_FAST = 6;
+constexpr int WT_FAST = 16, WTH_FAST = 64, WH_FAST = 3, WK_FAST = 6;
 constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 constexpr int LINE_LAB = -1;
 
@@ -317,23 +319,25 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         const int n = s_n[cur];
         if (n == 0) break;
         my_rounds++;
+        // at most 4 list entries per thread (n <= WT*WT = 4 * WS_THREADS); static indices keep cc/dec in registers
         int cc[4];
         Decision dec[4];
-        int cnt = 0;
-#pragma unroll 1
-        for (int i = threadIdx.x; i < n; i += WS_THREADS) {
-            const int c = slist[cur][i];
-            cc[cnt] = c;
-            dec[cnt].lab = 0; dec[cnt].ti = 0;
-            if (slab[c] == 0) { my_evals++; dec[cnt] = ws_decide(tv, c, certs); }
-            else cc[cnt] = -1;  // decided meanwhile (pushed by a neighbour in the round it was decided itself)
-            cnt++;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + j * WS_THREADS;
+            cc[j] = -1;
+            dec[j].lab = 0; dec[j].ti = 0;
+            if (i < n) {
+                const int c = slist[cur][i];
+                if (slab[c] == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, certs); }
+                // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
+            }
         }
         __syncthreads();  // every read of this round is done
         if (threadIdx.x == 0) { s_n[cur ^ 1] = 0; s_any = 0; }
         __syncthreads();
-#pragma unroll 1
-        for (int j = 0; j < cnt; ++j) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             const int c = cc[j];
             if (c < 0) continue;
             if (dec[j].lab == 0) {  // still waiting: stays on the frontier
