@@ -749,18 +749,25 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         int iter = 0, fallbacks = 0;
         bool wide = false, wide_after_endgame = false;
         int endgames = 0;
+        int burst_no = 0;
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-            unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
-            TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
-            if (!wide)
-                TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y, X,
-                           tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
-            else
-            {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
-                TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img, st, Y,
-                           X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, 1, 4096, info);
-                TIP_HIP(hipMemsetAsync(cur, 1, ntiles, s));
+            // tile launches go out in bursts with ONE host check per burst (a launch whose tiles are all inactive costs
+            // ~15 us, a host round trip ~50 us): 6 launches first, then 4, then 2 at a time
+            const int burst = wide ? 1 : (burst_no == 0 ? 6 : (burst_no == 1 ? 4 : 2));
+            burst_no++;
+            for (int rep = 0; rep < burst; ++rep) {
+                if (rep) ++iter;
+                unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
+                TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
+                if (!wide)
+                    TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y,
+                               X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+                else {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
+                    TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img,
+                               st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, 1, 4096, info);
+                    TIP_HIP(hipMemsetAsync(cur, 1, ntiles, s));
+                }
             }
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
