@@ -111,6 +111,8 @@ TIP_API int tip_label4_i32_dev(const int32_t *in, int32_t bg, int32_t *out, int 
 /* non-marker neighbours were met (FIFO order of the serial flood then not reproduced bit for bit). */
 TIP_API int tip_watershed_f64(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags);
 TIP_API int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host);
+/* number of labels (= markers) produced by the calling thread's last watershed call                 */
+TIP_API int tip_last_watershed_labels(void);
 /* bim.py:446-476 as one device pipeline: local threshold -> Gaussian(sigma) -> watershed          */
 TIP_API int tip_watershed_segmentation_f64_dev(const double *img, int32_t *labels, int y, int x, double imgthresh,
                                                const double *taps, int ntaps, int block, int32_t *flags_host);

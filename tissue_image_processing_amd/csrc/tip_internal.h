@@ -22,6 +22,7 @@ struct Ctx {
     // workspace pool: cached device blocks, best-fit reuse
     struct Block { void *p; size_t bytes; bool used; };
     std::vector<Block> pool;
+    int last_ws_labels = 0;   // marker count of this thread's last watershed (tip_last_watershed_labels)
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;

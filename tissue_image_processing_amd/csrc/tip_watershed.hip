@@ -711,6 +711,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     WsInfo h;
     TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
     TIP_HIP(hipStreamSynchronize(s));
+    c.last_ws_labels = h.n_markers;
     int flags = h.ties ? 1 : 0;
     const bool two_valued = h.n_other == 0 && h.emin != h.emax;
     if (h.n_markers > 0 && two_valued) {
@@ -853,6 +854,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
 using namespace tip;
 
 extern "C" {
+
+int tip_last_watershed_labels(void) { return ctx().last_ws_labels; }
 
 int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host)
 {

@@ -84,26 +84,28 @@ class FramePipeline:
         P = self.Y * self.X
         lab_ptr = self.d_labels.ptr if labels_ptr is None else labels_ptr
         LY, LX = (self.Y, self.X) if shape is None else shape
-        cap_cells = max_cells or max(1024, P // 64)
-        if getattr(self, "_tables", None) is None or self._tables[0] < cap_cells:
-            n = cap_cells
+        ncells = max_cells or int(self.lib.tip_last_watershed_labels())   # labels are 1..ncells
+        if ncells <= 0:
+            self.tables = dict(area=np.zeros(0, np.int64), bbox=np.zeros((0, 4), np.int64), sumy=np.zeros(0, np.int64),
+                               sumx=np.zeros(0, np.int64), pc=np.zeros((0, 3), np.int64), pairs=np.zeros((0, 2), np.int32))
+            return self.tables
+        if getattr(self, "_tables", None) is None or self._tables[0] < ncells:
+            n = max(1024, int(ncells * 1.5))
             self._tables = (n, _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 32), _lib.DeviceBuffer(n * 8),
                             _lib.DeviceBuffer(n * 8), _lib.DeviceBuffer(n * 24), _lib.DeviceBuffer(16 * n * 8))
-        n, d_area, d_bbox, d_sy, d_sx, d_pc, d_pairs = self._tables
+        cap, d_area, d_bbox, d_sy, d_sx, d_pc, d_pairs = self._tables
+        n = ncells
         _lib.check(self.lib.tip_regionprops_i32_dev(_lib.dptr(lab_ptr), None, LY, LX, n,
                                                     _lib.dptr(d_area.ptr), _lib.dptr(d_bbox.ptr), _lib.dptr(d_sy.ptr),
                                                     _lib.dptr(d_sx.ptr), _lib.dptr(d_pc.ptr), None))
         npairs = ctypes.c_int64(0)
         _lib.check(self.lib.tip_neighbor_pairs_i32_dev(_lib.dptr(lab_ptr), LY, LX,
-                                                       _lib.dptr(d_pairs.ptr), ctypes.c_int64(16 * n),
+                                                       _lib.dptr(d_pairs.ptr), ctypes.c_int64(16 * cap),
                                                        ctypes.byref(npairs)))
-        area = d_area.download((n,), np.int64)
-        ncells = int(np.max(np.nonzero(area)[0])) + 1 if area.any() else 0
         self.tables = dict(
-            area=area[:ncells], bbox=d_bbox.download((n, 4), np.int64)[:ncells],
-            sumy=d_sy.download((n,), np.int64)[:ncells], sumx=d_sx.download((n,), np.int64)[:ncells],
-            pc=d_pc.download((n, 3), np.int64)[:ncells],
-            pairs=d_pairs.download((16 * n, 2), np.int32)[:npairs.value])
+            area=d_area.download((n,), np.int64), bbox=d_bbox.download((n, 4), np.int64),
+            sumy=d_sy.download((n,), np.int64), sumx=d_sx.download((n,), np.int64),
+            pc=d_pc.download((n, 3), np.int64), pairs=d_pairs.download((max(int(npairs.value), 1), 2), np.int32)[:npairs.value])
         return self.tables
 
     def sync(self):
