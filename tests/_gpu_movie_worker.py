@@ -1,0 +1,33 @@
+"""Worker for the 2-process GPU movie test: both ranks drive the SAME GPU (device 0), collectives over gloo."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    from tissue_image_processing_amd import movie, synthetic
+    out_path = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    Z, Y, X, T = 6, 128, 160, 4
+    sites_t, is_hc = synthetic.make_movie_sites(Y, X, T, seed=7)
+    stacks = [synthetic.make_stack(Z, Y, X, seed=70 + t, sites=sites_t[t], is_hc=is_hc) for t in range(T)]
+    backend = movie.GpuFrameBackend(2, Z, Y, X, device=0)
+    drifts = np.zeros((T, 2))
+    drifts[1:] = (0.5, -0.3)
+    tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, dist if world > 1 else None, "cpu", drifts)
+    if rank == 0:
+        np.savez(out_path, n=T, **{"ids_%d" % t: ids[t] for t in range(T)}, **{"area_%d" % t: tabs[t]["area"] for t in range(T)})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -784,7 +784,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 for (int v2 : hu) und_total += v2;
             }
             if (und_total == 0) break;
-            if (!wide_after_endgame) {
+            if (!wide_after_endgame && !getenv("TIP_WS_NO_ENDGAME")) {   // (env: test hook that exercises the fallback machinery)
                 // serial rule on every small connected component of undecided pixels (one wave each, bounded steps)
                 SameU su{st};
                 if ((rc = uf_components(su, parent, Y, X))) return rc;
@@ -824,7 +824,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 wide = true;
                 continue;
             }
-            if (!wide) { wide = true; continue; }  // no progress with small pockets: one wide launch over every tile
+            if (!wide && !getenv("TIP_WS_NO_WIDE")) { wide = true; continue; }  // no progress: one wide launch over every tile
             wide = false;
             // still nothing: pockets too large to certify locally -> commit the pixel with the globally smallest pop time
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
