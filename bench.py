@@ -205,7 +205,7 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            Ys, Xs = min(Y, 1024), min(X, 1024)
+            Ys, Xs = min(Y, 1408), min(X, 1408)
             dt = cpu_baseline((Ys, Xs), Z, workload)
             scale = (Y * X) / float(Ys * Xs)
             out["cpu_baseline"] = {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": 1, "kind": "port",
