@@ -151,17 +151,17 @@ struct T2 { double v; int i; };
 __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
 
 struct TileView {
-    const double *sv;       // LDS: image values of the window
-    const int *slab, *sti;  // LDS: label / 0 / LINE, and pop-time reference pixel (global index) of labelled cells
-    const int *sgi;         // LDS: global linear index of every window cell
-    const double *gv;       // global image (pop-time value of pulled pixels = gv[tref])
-    unsigned short *vis;    // LDS: this thread's pocket list
-    int budget;             // pocket flood budget (cells)
-    int WL;                 // window edge (tile + 2 * halo)
+    const double *sv;                  // LDS: image values of the window
+    const unsigned long long *sst;     // LDS: packed state (label | pop-time reference pixel << 32)
+    const int *sgi;                    // LDS: global linear index of every window cell
+    const double *gv;                  // global image (pop-time value of pulled pixels = gv[tref])
+    unsigned short *vis;               // LDS: this thread's pocket list
+    int budget;                        // pocket flood budget (cells)
+    int WL;                            // window edge (tile + 2 * halo)
     __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], sgi[c]}; }
-    __device__ __forceinline__ T2 T(int c) const
+    __device__ __forceinline__ T2 Tof(int c, unsigned long long s) const
     {
-        const int tr = sti[c];
+        const int tr = st_tref(s);
         return T2{tr == sgi[c] ? sv[c] : gv[tr], tr};
     }
 };
@@ -169,8 +169,9 @@ struct TileView {
 // Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
 // key < t around q (breadth first, the per-thread list in LDS is queue and visited set at once); the pocket is closed
 // iff nothing labelled before t touches it.  Running out of budget or window is "cannot certify" (the pixel waits).
-__device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, const T2 &t)
+__device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, double tvv, int tii)
 {
+    const T2 t{tvv, tii};
     int nv = 1, head = 0;
     const int WL = tv.WL;
     tv.vis[0] = (unsigned short)q;
@@ -178,14 +179,15 @@ __device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, const
         const int c = tv.vis[head++];
         const int cy = c / WL, cx = c - cy * WL;
         if (cy == 0 || cy == WL - 1 || cx == 0 || cx == WL - 1) return false;  // neighbours outside the window
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             const int m = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
             if (m == asker) continue;
-            const int l = tv.slab[m];
+            const unsigned long long sm = tv.sst[m];
+            const int l = st_lab(sm);
             if (l == LINE_LAB) continue;
             if (l > 0) {
-                if (t_lt(tv.T(m), t)) return false;
+                if (t_lt(tv.Tof(m, sm), t)) return false;
             } else if (t_lt(tv.key(m), t)) {
                 bool seen = false;
                 for (int j = 0; j < nv; ++j) seen |= tv.vis[j] == (unsigned short)m;
@@ -201,58 +203,75 @@ __device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, const
 
 struct Decision { int lab; int ti; };  // lab == 0: no decision; ti = pop-time reference pixel
 
-// certs == false: cheap rule, any undecided neighbour that could pop earlier makes the pixel wait (the common case:
-// that neighbour is simply not processed yet).  certs == true: such neighbours are examined with ws_cert, which is what
-// resolves genuinely stuck pockets; the tile loop only asks for it after a round without progress.
+// The flood rule for one undecided cell, written for few instructions: all LDS loads first, then predicated
+// arithmetic; the pocket certificates (rare) are the only calls.  certs == false: any undecided neighbour that could
+// pop earlier makes the pixel wait (the common case: that neighbour is simply not processed yet).
 __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool certs)
 {
     Decision d{0, 0};
     const int WL = tv.WL;
-    const int l0 = tv.slab[c - WL], l1 = tv.slab[c - 1], l2 = tv.slab[c + 1], l3 = tv.slab[c + WL];
+    const int q0 = c - WL, q1 = c - 1, q2 = c + 1, q3 = c + WL;
+    const unsigned long long s0 = tv.sst[q0], s1 = tv.sst[q1], s2 = tv.sst[q2], s3 = tv.sst[q3];
+    const int l0 = st_lab(s0), l1 = st_lab(s1), l2 = st_lab(s2), l3 = st_lab(s3);
     if (!(l0 > 0 || l1 > 0 || l2 > 0 || l3 > 0)) return d;
-    const T2 kp = tv.key(c);
-    int s_lab = 0;
-    bool conflict = false, has_pull = false, wait = false;
-    T2 pull_t{0.0, 0};
-    int pull_lab = 0;
-    unsigned und_mask = 0;
+    const double v0 = tv.sv[q0], v1 = tv.sv[q1], v2 = tv.sv[q2], v3 = tv.sv[q3], vc = tv.sv[c];
+    const int g0 = tv.sgi[q0], g1 = tv.sgi[q1], g2 = tv.sgi[q2], g3 = tv.sgi[q3], gc = tv.sgi[c];
+    int s_lab = 0, pull_lab = 0, pull_ti = 0;
+    bool conflict = false, has_pull = false;
+    double pull_tv = 0.0;
+    unsigned early_u = 0, und = 0;   // bit k: undecided neighbour k (that could pop before this cell)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+        const unsigned long long sq = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
         const int l = k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));
+        const int gq = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+        double tq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
         if (l == LINE_LAB) continue;
+        int ti = gq;
         if (l > 0) {
-            const T2 tq = tv.T(q);
-            if (t_lt(tq, kp)) {
+            ti = st_tref(sq);
+            if (ti != gq) tq = tv.gv[ti];   // pulled pixel: its pop time is another pixel's key (rare)
+        }
+        const bool before = tq < vc || (tq == vc && ti < gc);
+        if (l > 0) {
+            if (before) {
                 if (s_lab == 0) s_lab = l;
                 else if (s_lab != l) conflict = true;
-            } else if (!has_pull || t_lt(tq, pull_t)) {
-                has_pull = true; pull_t = tq; pull_lab = l;
+            } else if (!has_pull || tq < pull_tv || (tq == pull_tv && ti < pull_ti)) {
+                has_pull = true; pull_tv = tq; pull_ti = ti; pull_lab = l;
             }
         } else {
-            und_mask |= 1u << k;
-            if (t_lt(tv.key(q), kp)) {
-                if (!certs) wait = true;
-                else if (!ws_cert(tv, q, c, kp)) wait = true;
-            }
+            und |= 1u << k;
+            if (before) early_u |= 1u << k;
         }
     }
-    if (wait) return d;
+    if (early_u) {
+        if (!certs) return d;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k)
+            if ((early_u >> k) & 1u) {
+                const int q = k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+                if (!ws_cert(tv, q, c, vc, gc)) return d;
+            }
+    }
     if (s_lab != 0) {
         d.lab = conflict ? LINE_LAB : s_lab;
-        d.ti = kp.i;
+        d.ti = gc;
         return d;
     }
     if (!has_pull) return d;
-#pragma unroll
+    // stuck pixel: it is pulled by its earliest-labelled neighbour unless another neighbour can still get there first
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        if (!((und_mask >> k) & 1u)) continue;
-        const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
-        if (t_lt(pull_t, tv.key(q))) continue;
+        if (!((und >> k) & 1u)) continue;
+        const int q = k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+        const double vq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
+        const int gq = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+        if (pull_tv < vq || (pull_tv == vq && pull_ti < gq)) continue;   // q cannot pop before the pull
         if (!certs) return d;
-        if (!ws_cert(tv, q, c, pull_t)) return d;
+        if (!ws_cert(tv, q, c, pull_tv, pull_ti)) return d;
     }
-    d.lab = pull_lab; d.ti = pull_t.i;
+    d.lab = pull_lab; d.ti = pull_ti;
     return d;
 }
 
@@ -267,8 +286,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
 {
     constexpr int WL = WT + 2 * WH;
     __shared__ double sv[WL * WL];
-    __shared__ int slab[WL * WL];
-    __shared__ int sti[WL * WL];
+    __shared__ unsigned long long sst[WL * WL];     // label | pop-time reference pixel << 32, one 8-byte word
     __shared__ int sgi[WL * WL];
     __shared__ int sinl[WL * WL];
     __shared__ unsigned short svis[WS_THREADS * WK];
@@ -292,22 +310,22 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         const int gy = gy0 + ly, gx = gx0 + lx;
         sinl[c] = 0;
         if (gy < 0 || gy >= Y || gx < 0 || gx >= X) {
-            slab[c] = LINE_LAB; sv[c] = 0.0; sti[c] = 0; sgi[c] = -1;
+            sst[c] = pack_st(LINE_LAB, 0); sv[c] = 0.0; sgi[c] = -1;
         } else {
             const int gi = gy * X + gx;
-            const unsigned long long s = st[gi];
-            sv[c] = v[gi]; slab[c] = st_lab(s); sti[c] = st_tref(s); sgi[c] = gi;
+            sv[c] = v[gi]; sst[c] = st[gi]; sgi[c] = gi;
         }
     }
     if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; }
     __syncthreads();
-    TileView tv{sv, slab, sti, sgi, v, svis + threadIdx.x * WK, WK, WL};
+    TileView tv{sv, sst, sgi, v, svis + threadIdx.x * WK, WK, WL};
     // initial frontier: undecided interior cells next to a labelled cell
 #pragma unroll 1
     for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
-        if (slab[c] == 0 && (slab[c - WL] > 0 || slab[c - 1] > 0 || slab[c + 1] > 0 || slab[c + WL] > 0)) {
+        if (st_lab(sst[c]) == 0 && (st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 ||
+                                    st_lab(sst[c + WL]) > 0)) {
             sinl[c] = 1;
             slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
         }
@@ -329,7 +347,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             dec[j].lab = 0; dec[j].ti = 0;
             if (i < n) {
                 const int c = slist[cur][i];
-                if (slab[c] == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, certs); }
+                if (st_lab(sst[c]) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, certs); }
                 // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
             }
         }
@@ -344,7 +362,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
                 continue;
             }
-            slab[c] = dec[j].lab; sti[c] = dec[j].ti; sinl[c] = 0;
+            sst[c] = pack_st(dec[j].lab, dec[j].ti); sinl[c] = 0;
             s_any = 1;
             atomicAdd(&s_chg, 1);
             if (dec[j].lab > 0) {
@@ -352,7 +370,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 for (int k = 0; k < 4; ++k) {
                     const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
                     const int qy = q / WL, qx = q - qy * WL;
-                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && slab[q] == 0 && atomicExch(&sinl[q], 1) == 0)
+                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && st_lab(sst[q]) == 0 && atomicExch(&sinl[q], 1) == 0)
                         slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
                 }
             }
@@ -371,9 +389,9 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         const int c = (p / WT + WH) * WL + (p % WT + WH);
         const int gi = sgi[c];
         if (gi >= 0) {
-            const int l = slab[c];
-            if (l == 0) und++;
-            else if (st_lab(st[gi]) == 0) st[gi] = pack_st(l, sti[c]);
+            const unsigned long long sc = sst[c];
+            if (st_lab(sc) == 0) und++;
+            else if (st_lab(st[gi]) == 0) st[gi] = sc;
         }
     }
     if (und) atomicAdd(&s_und, und);
