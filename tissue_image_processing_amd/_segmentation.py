@@ -31,8 +31,8 @@ def watershed_segmentation(image, imgthresh, stdeviation, blocksize, return_flag
     image = np.asarray(image)
     if image.ndim != 2:
         raise ValueError("watershed_segmentation takes a 2-D image")
-    if image.dtype not in (np.float32, np.float64):
-        raise TypeError("watershed_segmentation on MI355X takes float32/float64 images (got %s)" % image.dtype)
+    if image.dtype not in (np.float32, np.float64) and not np.issubdtype(image.dtype, np.integer):
+        raise TypeError("watershed_segmentation on MI355X takes float or integer images (got %s)" % image.dtype)
     if blocksize % 2 == 0:
         blocksize += 1
     lib = _lib.lib()
@@ -52,7 +52,8 @@ def watershed_segmentation(image, imgthresh, stdeviation, blocksize, return_flag
         d_img.free()
         d_lab.free()
     else:
-        # float32 image: the reference keeps the image dtype through thresholding and blurring (bim.py:463-474)
+        # float32 / integer image: the reference keeps the image dtype through thresholding and blurring
+        # (bim.py:463-474); integer-valued landscapes have value ties, see the `flags` bit0 note in watershed()
         from .basic_image_manipulations import blur_image
         img64 = np.ascontiguousarray(image, dtype=np.float64)
         mx = np.empty_like(img64)

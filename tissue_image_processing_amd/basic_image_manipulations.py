@@ -72,14 +72,23 @@ def blur_image(image, std):
     if image.ndim < 1 or image.ndim > 3:
         raise ValueError("blur_image on MI355X supports rank 1..3 arrays (got rank %d)" % image.ndim)
     sig = _normalize_sigma(std, image.ndim)
+    if np.issubdtype(image.dtype, np.integer) or image.dtype == bool:
+        # scipy keeps the input dtype: every axis pass accumulates in double and the C core casts the result back to
+        # the integer type (truncation toward zero) before the next axis sees it
+        cur = image.astype(np.float64)
+        for ax in range(image.ndim):
+            if sig[ax] > 1e-15:
+                one = np.zeros(image.ndim)
+                one[ax] = sig[ax]
+                cur = np.trunc(blur_image(cur, tuple(one)))
+        return cur.astype(image.dtype)
     src = image
     if image.dtype == np.float32:
         dtype = 0
     elif image.dtype == np.float64:
         dtype = 1
     else:
-        raise TypeError("blur_image on MI355X supports float32/float64 images (got %s); "
-                        "the reference only blurs float arrays on this path" % image.dtype)
+        raise TypeError("blur_image on MI355X supports float32/float64/integer images (got %s)" % image.dtype)
     src = np.ascontiguousarray(src)
     if src.size == 0:
         return src.copy()
