@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight per GPU: host threads, each with its own HIP stream and workspaces (the library "
+                         "is re-entrant per thread, like the reference's Qt workers); frames are independent units")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,77 +124,156 @@ def main():
         workload = "classical" if has_seg else "projection"
 
     # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
+    import threading
     st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
-    pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(workload == "unet"))
-    predictor = None
-    if workload == "unet":
-        from tissue_image_processing_amd.prediction_local import SegmentationPredictor
-        predictor = SegmentationPredictor(None, (2, X, Y), device=local_rank)  # random-init weights (none ship upstream)
-    frames = [pipe.upload_stack(st), pipe.upload_stack(np.ascontiguousarray(st[:, :, :, ::-1]))]
-    del st
+    st_flip = np.ascontiguousarray(st[:, :, :, ::-1])
+    nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else 1
 
-    def step(i):
-        pipe.project(frames[i % 2])
-        if workload == "classical":
-            pipe.segment(0)
-            pipe.cell_tables()
-        elif workload == "unet":
-            lab, _ = pipe.segment_unet(predictor)
-            pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
+    class Worker(object):
+        """One frame in flight: own thread, own HIP stream / workspace pool (tip_init per thread), own resident buffers."""
+
+        def __init__(self, wid):
+            self.wid = wid
+            self.todo = threading.Semaphore(0)
+            self.done = threading.Semaphore(0)
+            self.jobs = []
+            self.report = {}
+            self.thread = threading.Thread(target=self.run, daemon=True)
+            self.thread.start()
+            self.done.acquire()  # wait for setup
+
+        def run(self):
+            _lib.init(local_rank)
+            self.pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(workload == "unet"))
+            self.predictor = None
+            if workload == "unet":
+                from tissue_image_processing_amd.prediction_local import SegmentationPredictor
+                self.predictor = SegmentationPredictor(None, (2, X, Y), device=local_rank)  # random-init (none ship upstream)
+            self.frames = [self.pipe.upload_stack(st), self.pipe.upload_stack(st_flip)]
+            self.done.release()
+            while True:
+                self.todo.acquire()
+                job = self.jobs.pop(0)
+                if job is None:
+                    return
+                kind, arg = job
+                if kind == "steps":
+                    for i in arg:
+                        self.step(i)
+                    self.pipe.sync()
+                elif kind == "prof":
+                    if arg == "on":
+                        _lib.prof_reset()
+                        _lib.prof_enable(True)
+                    else:
+                        _lib.prof_enable(False)
+                        self.report = _lib.prof_report()
+                self.done.release()
+
+        def step(self, i):
+            pipe = self.pipe
+            pipe.project(self.frames[i % 2])
+            if workload == "classical":
+                pipe.segment(0)
+                pipe.cell_tables()
+            elif workload == "unet":
+                lab, _ = pipe.segment_unet(self.predictor)
+                pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
+
+        def submit(self, job):
+            self.jobs.append(job)
+            self.todo.release()
+
+        def wait(self):
+            self.done.acquire()
+
+    workers = [Worker(w) for w in range(nthreads)]
+    del st, st_flip
+
+    def run_steps(n):
+        for w in workers:
+            w.submit(("steps", list(range(w.wid, n, nthreads))))
+        for w in workers:
+            w.wait()
+
+    def all_workers(job):
+        for w in workers:
+            w.submit(job)
+        for w in workers:
+            w.wait()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        pipe.sync()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(max(args.warmup, nthreads))
     barrier()
-    _lib.prof_reset()
-    _lib.prof_enable(True)
+    all_workers(("prof", "on"))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    _lib.prof_enable(False)
+    all_workers(("prof", "off"))
+    timed_reports = [dict(w.report) for w in workers]
+    # isolated pass for the roofline: ONE frame in flight, so that a kernel's duration is its own (with several frames in
+    # flight kernels of different frames share the chip and every per-kernel duration is inflated)
+    iso_steps = min(args.steps, 5)
+    workers[0].submit(("prof", "on")); workers[0].wait()
+    workers[0].submit(("steps", list(range(iso_steps)))); workers[0].wait()
+    workers[0].submit(("prof", "off")); workers[0].wait()
+    iso_report = dict(workers[0].report)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        rep = _lib.prof_report()
-        total_kernel_ms = sum(v[1] for v in rep.values())
-        dom = max(rep.items(), key=lambda kv: kv[1][1])
-        name, (cnt, ms) = dom
-        avg_s = ms / cnt / 1e3
-        ab = algorithmic_bytes(name, C, Z, Y, X)
-        roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                "traffic": None, "avg_launch_ms": ms / cnt, "launches": cnt,
-                "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
-        roof["traffic"] = pmc_traffic(name)
-        if ab:
-            roof["achieved"] = ab / avg_s / 1e9
-            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-            roof["algorithmic_bytes"] = ab
-        ops = algorithmic_dp_ops(name, Z, Y, X)
-        if ops:
-            # honest second bound: this kernel is FP64-VALU bound by construction (exact scipy arithmetic)
-            tf = ops / avg_s / 1e12
-            roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
-                                 "frac": tf / (FP64_VALU_PEAK_TF / 2),
-                                 "note": "separately rounded mul/add: one lane-op per instruction, peak = FMA peak / 2"}
-        kernels = {}
-        for k, v in rep.items():
-            kernels[k] = {"n": v[0], "ms_total": round(v[1], 4)}
-            kb = algorithmic_bytes(k, C, Z, Y, X)
-            if kb:
-                gbs = kb / (v[1] / v[0] / 1e3) / 1e9
-                kernels[k]["hbm_GBps"] = round(gbs, 1)
-                kernels[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        def merge(reports):
+            rep = {}
+            for r in reports:
+                for k, (cnt_k, ms_k) in r.items():
+                    c0, m0 = rep.get(k, (0, 0.0))
+                    rep[k] = (c0 + cnt_k, m0 + ms_k)
+            return rep
+
+        def roofline_of(rep):
+            total_kernel_ms = sum(v[1] for v in rep.values())
+            name, (cnt, ms) = max(rep.items(), key=lambda kv: kv[1][1])
+            avg_s = ms / cnt / 1e3
+            ab = algorithmic_bytes(name, C, Z, Y, X)
+            roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": pmc_traffic(name), "avg_launch_ms": ms / cnt, "launches": cnt,
+                    "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
+            if ab:
+                roof["achieved"] = ab / avg_s / 1e9
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                roof["algorithmic_bytes"] = ab
+            ops = algorithmic_dp_ops(name, Z, Y, X)
+            if ops:
+                tf = ops / avg_s / 1e12
+                roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
+                                     "frac": tf / (FP64_VALU_PEAK_TF / 2)}
+            return roof
+
+        def kernel_table(rep, nsteps):
+            out_k = {}
+            for k, v in rep.items():
+                out_k[k] = {"n_per_step": round(v[0] / nsteps, 2), "ms_per_step": round(v[1] / nsteps, 4)}
+                kb = algorithmic_bytes(k, C, Z, Y, X)
+                if kb:
+                    gbs = kb / (v[1] / v[0] / 1e3) / 1e9
+                    out_k[k]["hbm_GBps"] = round(gbs, 1)
+                    out_k[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+            return out_k
+
+        roof = roofline_of(iso_report)
+        roof["measured"] = ("HIP events on the library stream, isolated pass of %d steps with ONE frame in flight run right "
+                            "after the timed region (kernels of concurrent frames share the chip in the timed region)" % iso_steps)
+        timed = merge(timed_reports)
+        roof_timed = roofline_of(timed)
+        kernels = kernel_table(iso_report, iso_steps)
         out = {
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -201,8 +283,9 @@ def main():
                 "projection": "surface_projection",
                 "classical": "surface_projection+watershed_segmentation+cell_tables",
                 "unet": "surface_projection+unet_segmentation(%s,random-init)+cell_tables" % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}[workload]),
-                "frames_per_step": world, "parallelism": "frame-sharded dp%d, no data-path collective" % world},
-            "roofline": roof, "kernels": kernels,
+                "frames_per_step": world, "frames_in_flight_per_gpu": nthreads,
+                "parallelism": "frame-sharded dp%d, no data-path collective" % world},
+            "roofline": roof, "roofline_timed_region": roof_timed, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             Ys, Xs = min(Y, 1408), min(X, 1408)
