@@ -89,13 +89,55 @@ def cpu_baseline(sample_yx, Z, workload):
     return dt
 
 
+def bench_movie(args, rank, local_rank, world, dist, torch):
+    """BASELINE config 4 in miniature: a time-lapse of `steps` frames per GPU sharded frame t -> rank t % world, every
+    frame through projection -> segmentation -> cell tables, then the track stitching exchange (all-gather of centroid
+    tables, owner-side label look-ups, gather of the index arrays to rank 0 over RCCL, sequential id propagation)."""
+    from tissue_image_processing_amd import movie, synthetic
+    Y, X, Z = args.size
+    T = args.steps * world
+    sites_t, is_hc = synthetic.make_movie_sites(Y, X, T, seed=5)
+    mine = list(range(rank, T, world))
+    stacks = {t: synthetic.make_stack(Z, Y, X, seed=200 + t, sites=sites_t[t], is_hc=is_hc) for t in mine}
+    backend = movie.GpuFrameBackend(2, Z, Y, X, device=local_rank)
+    backend.process_frame(-1, stacks[mine[0]])        # warm-up (allocations)
+    drifts = np.zeros((T, 2))
+    drifts[1:] = (0.5, -0.3)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, dist if world > 1 else None,
+                                    torch.device("cuda", local_rank) if world > 1 else "cpu", drifts)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n_tracks = int(max(i.max() for i in ids))
+        print(json.dumps({
+            "metric": "frames/sec end-to-end (2048^2, z=30)", "value": T / elapsed, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d_c2_u16:movie(%d frames, host upload included)+track_stitching" % (Y, X, Z, T),
+                       "parallelism": "frame-sharded dp%d, RCCL gather of per-frame tables to rank 0" % world,
+                       "tracks": n_tracks, "cells_last_frame": int(ids[-1].size)}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
-    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: host threads, each with its own HIP stream and workspaces (the library "
@@ -115,6 +157,8 @@ def main():
     from tissue_image_processing_amd import _lib, synthetic
     from tissue_image_processing_amd.pipeline import FramePipeline
     _lib.init(local_rank)
+    if args.workload == "movie":
+        return bench_movie(args, rank, local_rank, world, dist, torch)
     lib = _lib.lib()
     Y, X, Z = args.size
     C = 2

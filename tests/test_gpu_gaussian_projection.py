@@ -185,3 +185,19 @@ def test_certified_argmax_equals_exact_score_path(mods, monkeypatch):
         monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE", raising=False)
         assert int((z_c != z_e).sum()) == 0
         np.testing.assert_array_equal(p_c, p_e)
+
+
+def test_baseline_config_sizes_vs_oracle(mods):
+    """BASELINE.json configs[0] (512x512, z=10) and configs[1] (1024x1024, z=20): projection + Gaussian on the GPU
+    diffed against the CPU oracle -- required tolerance 1e-5 relative, achieved: bit-identical."""
+    bim, sp, orc = mods
+    from tissue_image_processing_amd import synthetic
+    for (Z, Y, X, seed) in [(10, 512, 512, 31), (20, 1024, 1024, 32)]:
+        st = synthetic.make_stack(Z, Y, X, seed=seed)
+        p_ref, z_ref = orc.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, z_map=True)
+        p, z = sp.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, z_map=True)
+        assert int((z != z_ref).sum()) == 0
+        np.testing.assert_allclose(p, p_ref, rtol=1e-5, atol=0)
+        np.testing.assert_array_equal(p, p_ref)
+        vol = st[0].astype(np.float32)
+        np.testing.assert_array_equal(bim.blur_image(vol, (0.5, 1, 1)), orc.blur_image(vol, (0.5, 1, 1)))
