@@ -44,8 +44,8 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
     return table.get(kernel)
 
 
-PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r01c_pmc_traffic.json
-    "ws_tiles": "k_ws_tiles<3, 6>", "score_fast_y": "k_corr_long_fast<1", "score_fast_x": "k_corr_long_fast<2",
+PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r01d_pmc_traffic.json
+    "ws_tiles": "k_ws_tiles<16, 64, 3, 6>", "score_fast_y": "k_corr_long_fast<1", "score_fast_x": "k_corr_long_fast<2",
     "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
     "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",
     "regionprops": "k_regionprops", "hist_u16": "k_hist_u16", "mask_y_sparse": "k_mask_y_sparse",
@@ -56,7 +56,7 @@ PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in separate
     runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
     key = PMC_NAMES.get(kernel)
     if not key or not os.path.exists(path):
         return None
