@@ -87,37 +87,40 @@ def _gather_to_root(flat, dist, rank, world, device):
     return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
 
 
-def propagate_ids(tables, lookups):
-    """Sequential part of track_cells_iterator (ti.py:2041-2110) on rank 0.
+def assign_track_ids(prev_ids, hit, n_cur, start_ids=None):
+    """One step of the label-lookup tracker's id bookkeeping (ti.py:2041-2046, 2092-2106).
 
-    tables[t]: dict(area, cy, cx) over row index = label-1; lookups[t] (t >= 1): for every row of frame t-1 the value
-    of the 3x3-max-filtered label map of frame t at its drift-corrected centroid (-1 = outside).  Returns the
-    per-frame id arrays exactly as the reference leaves them in cells_info.label."""
-    n0 = tables[0]["area"].size
-    # calculate_frame_cellinfo leaves label = row+1 for present rows, 0 for absent ones (ti.py:893)
-    ids0 = np.where(tables[0]["area"] > 0, np.arange(1, n0 + 1), 0).astype(np.int64)
-    unl = ids0 == 0
-    last = ids0.max() if n0 else 0
-    ids0[unl] = np.arange(last + 1, last + unl.sum() + 1)
-    out = [ids0]
-    ids_prev = ids0
-    for t in range(1, len(tables)):
-        n_cur = tables[t]["area"].size
+    prev_ids[i] = track id of row i of the previous frame; hit[i] = label (row + 1) of the current frame found under
+    that row's drift-corrected centroid, 0 / -1 when nothing was hit.  Each previous id is handed on at most once and
+    each current row receives at most one id (first occurrence in np.unique order, as upstream); rows left without an
+    id get fresh ones above the largest id in use.  With start_ids the step only fills the zeros (first frame)."""
+    if start_ids is not None:
+        ids = np.asarray(start_ids, dtype=np.int64).copy()
+    else:
         ids = np.zeros(n_cur, np.int64)
-        idx = lookups[t].astype(np.float64) - 1
-        idx[lookups[t] < 0] = -1
-        lp = ids_prev[idx >= 0]
-        idx = idx[idx >= 0]
-        _, loc = np.unique(lp, return_index=True)
-        idx, lp = idx[loc], lp[loc]
-        _, loc = np.unique(idx, return_index=True)
-        idx, lp = idx[loc], lp[loc]
-        ids[idx.astype(int)] = lp
-        unl = ids == 0
-        last = ids.max() if n_cur else 0
-        ids[unl] = np.arange(last + 1, last + unl.sum() + 1)
-        out.append(ids)
-        ids_prev = ids
+        row = np.asarray(hit, dtype=np.int64) - 1
+        sel = row >= 0
+        carried, row = np.asarray(prev_ids)[sel], row[sel]
+        _, first = np.unique(carried, return_index=True)      # a previous id is used once ...
+        carried, row = carried[first], row[first]
+        _, first = np.unique(row, return_index=True)          # ... and a current row is claimed once
+        ids[row[first]] = carried[first]
+    fresh = ids == 0
+    top = ids.max() if ids.size else 0
+    ids[fresh] = np.arange(top + 1, top + fresh.sum() + 1)
+    return ids
+
+
+def propagate_ids(tables, lookups):
+    """Sequential part of the tracker on rank 0.  tables[t]: dict(area, cy, cx) over row index = label - 1;
+    lookups[t] (t >= 1): for every row of frame t-1 the 3x3-max-filtered label of frame t under its drift-corrected
+    centroid (-1 = outside / absent row).  Returns the per-frame id arrays as the reference leaves them in cells_info.label."""
+    n0 = tables[0]["area"].size
+    # calculate_frame_cellinfo leaves label = row + 1 for present rows and 0 for absent ones (ti.py:893)
+    first = np.where(tables[0]["area"] > 0, np.arange(1, n0 + 1), 0)
+    out = [assign_track_ids(None, None, n0, start_ids=first)]
+    for t in range(1, len(tables)):
+        out.append(assign_track_ids(out[-1], lookups[t], tables[t]["area"].size))
     return out
 
 

@@ -274,70 +274,54 @@ class TissueHipMixin(object):
 
     # ---- T3 -------------------------------------------------------------------------------------------------
     def track_cells_iterator(self, initial_frame=1, final_frame=-1, images=None, image_in_memory=False, use_piv=False):
+        """ti.py:2037-2113, the label-lookup tracker: the previous frame's centroids (drift-corrected) are looked up in
+        the current frame's 3x3-max-filtered label map, ids propagate one-to-one, unmatched cells get fresh ids.
+        Generator yielding the frame numbers it finished, like the reference."""
         if use_piv:
             raise NotImplementedError("optical-flow (PIV) drift is out of scope (SURVEY.md 8f)")
-        if final_frame == -1:
-            final_frame = self.number_of_frames
-        cells_info = self.get_cells_info(initial_frame)
-        if cells_info is None:
+        from .movie import assign_track_ids
+        last = self.number_of_frames if final_frame == -1 else final_frame
+        table = self.get_cells_info(initial_frame)
+        if table is None:
             return 0
-        unlabeled_cells = (cells_info.label.to_numpy() == 0)
-        last_used_label = cells_info.label.max()
-        cells_info.loc[unlabeled_cells, "label"] = np.arange(last_used_label + 1,
-                                                            last_used_label + np.sum(unlabeled_cells.astype(int)) + 1)
-        cx_previous_frame = np.copy(cells_info.cx.to_numpy())
-        cy_previous_frame = np.copy(cells_info.cy.to_numpy())
-        labels_previous_frame = cells_info.label.to_numpy()
-        empty_cells_previous_frame = cells_info.empty_cell.to_numpy()
-        previous_frame = initial_frame
-        self.cells_number = max(self.cells_number, cells_info.label.max())
-        use_existing_drifts = (self.drifts > 0).any()
-        update_next_drift = False
-        for frame in range(initial_frame + 1, final_frame + 1):
-            if self.valid_frames[frame - 1] == 0:
+        ids = table.label.to_numpy().astype(np.int64)
+        ids = assign_track_ids(None, None, ids.size, start_ids=ids)
+        table.loc[:, "label"] = ids
+        prev = dict(cx=table.cx.to_numpy().astype(np.float64).copy(), cy=table.cy.to_numpy().astype(np.float64).copy(),
+                    ids=ids, empty=table.empty_cell.to_numpy(), frame=initial_frame)
+        self.cells_number = max(self.cells_number, ids.max() if ids.size else 0)
+        reuse_drifts = bool((self.drifts > 0).any())
+        refresh_next = False
+        for frame in range(initial_frame + 1, last + 1):
+            if self.valid_frames[frame - 1] == 0:           # skipped frame: its drift is void, the next one is re-estimated
                 if not np.isnan(self.drifts[frame - 1, 0]):
                     self.drifts[frame - 1, :] = np.nan
-                    update_next_drift = True
+                    refresh_next = True
                 continue
-            if use_existing_drifts and not update_next_drift:
-                cx_previous_frame -= self.drifts[frame - 1, 1]
-                cy_previous_frame -= self.drifts[frame - 1, 0]
+            if reuse_drifts and not refresh_next:
+                dy, dx = self.drifts[frame - 1, 0], self.drifts[frame - 1, 1]
             else:
-                shift_y, shift_x = self.update_drift(frame, previous_frame, images=images, image_in_memory=image_in_memory)
-                cx_previous_frame -= shift_x
-                cy_previous_frame -= shift_y
-            cells_info = self.get_cells_info(frame)
+                dy, dx = self.update_drift(frame, prev["frame"], images=images, image_in_memory=image_in_memory)
+            prev["cx"] -= dx
+            prev["cy"] -= dy
+            table = self.get_cells_info(frame)
             raw = self.get_labels(frame)
-            if cells_info is None or raw is None:
+            if table is None or raw is None:
                 continue
-            labels = seg.maximum_filter(np.ascontiguousarray(raw, dtype=np.int32), (3, 3), mode="constant")
-            cells_info.loc[:, "label"] = 0
-            indices_in_current_frame = -1 * np.ones(cy_previous_frame.shape)
-            y_locations = np.round(cy_previous_frame).astype(int)
-            x_locations = np.round(cx_previous_frame).astype(int)
-            valid_locations = np.logical_and(np.logical_and(np.logical_and(0 <= y_locations, y_locations < labels.shape[0]),
-                                             np.logical_and(0 <= x_locations, x_locations < labels.shape[1])),
-                                             empty_cells_previous_frame == 0)
-            indices_in_current_frame[valid_locations] = labels[y_locations[valid_locations], x_locations[valid_locations]] - 1
-            labels_previous_frame = labels_previous_frame[indices_in_current_frame >= 0]
-            indices_in_current_frame = indices_in_current_frame[indices_in_current_frame >= 0]
-            _, loc = np.unique(labels_previous_frame, return_index=True)
-            indices_in_current_frame = indices_in_current_frame[loc]
-            labels_previous_frame = labels_previous_frame[loc]
-            _, loc = np.unique(indices_in_current_frame, return_index=True)
-            indices_in_current_frame = indices_in_current_frame[loc]
-            labels_previous_frame = labels_previous_frame[loc]
-            cells_info.loc[indices_in_current_frame.astype("int"), "label"] = labels_previous_frame
-            unlabeled_cells = (cells_info.label.to_numpy() == 0)
-            last_used_label = cells_info.label.max()
-            cells_info.loc[unlabeled_cells, "label"] = np.arange(last_used_label + 1,
-                                                                last_used_label + np.sum(unlabeled_cells.astype(int)) + 1)
-            self.cells_number = max(self.cells_number, cells_info.label.max())
-            cx_previous_frame = np.copy(cells_info.cx.to_numpy())
-            cy_previous_frame = np.copy(cells_info.cy.to_numpy())
-            labels_previous_frame = cells_info.label.to_numpy()
-            empty_cells_previous_frame = cells_info.empty_cell.to_numpy()
-            previous_frame = frame
+            lab = np.ascontiguousarray(raw, dtype=np.int32)
+            qy = np.round(prev["cy"]).astype(np.int64)
+            qx = np.round(prev["cx"]).astype(np.int64)
+            hit = np.empty(qy.shape, np.int32)
+            d_lab = _lib.DeviceBuffer(lab.nbytes).upload(lab)
+            _lib.check(_lib.lib().tip_lookup_max3_i32_dev(_lib.dptr(d_lab.ptr), lab.shape[0], lab.shape[1], _lib.ptr(qy),
+                                                         _lib.ptr(qx), ctypes.c_int64(qy.size), _lib.ptr(hit)))
+            d_lab.free()
+            hit = np.where(prev["empty"] == 0, hit, -1)
+            ids = assign_track_ids(prev["ids"], hit, table.shape[0])
+            table.loc[:, "label"] = ids
+            self.cells_number = max(self.cells_number, ids.max() if ids.size else 0)
+            prev = dict(cx=table.cx.to_numpy().astype(np.float64).copy(), cy=table.cy.to_numpy().astype(np.float64).copy(),
+                        ids=ids, empty=table.empty_cell.to_numpy(), frame=frame)
             yield frame
         return 0
 
