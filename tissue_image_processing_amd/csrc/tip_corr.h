@@ -42,6 +42,44 @@ __global__ void __launch_bounds__(256) k_corr_generic(Load in, T *__restrict__ o
     out[((long)z * Y + y) * X + x] = (T)tmp;
 }
 
+// Stage a (positions x 64 lines) float tile into LDS with 'nearest' clamping.  A block owns its CU's LDS alone, so
+// nothing else hides the HBM latency of this phase: every wave keeps 8 (AXIS 1) or 16 (AXIS 2) loads in flight
+// before the first LDS write.  first = plane coordinate of tile position 0 along the filter axis.
+template <int AXIS, int NW>
+__device__ __forceinline__ void stage_tile(float *tile, const float *__restrict__ src, int npos, int first, int l0, int Y, int X,
+                                           int lane, int wave)
+{
+    constexpr int LS = AXIS == 1 ? 64 : 65;
+    if (AXIS == 1) {
+        constexpr int UL = 8;
+        const int xx = min(l0 + lane, X - 1);
+        for (int pb = wave; pb < npos; pb += NW * UL) {
+            float v[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) v[u] = src[(long)clampi(first + pb + u * NW, 0, Y - 1) * X + xx];
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (pb + u * NW < npos) tile[(pb + u * NW) * LS + lane] = v[u];
+        }
+    } else {
+        // npos <= 256 + 2*127 < 512: eight 64-wide chunks cover a line; two lines per trip
+        for (int l = wave; l < 64; l += 2 * NW) {
+            float v[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int yy = min(l0 + l + h * NW, Y - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[h][u] = src[(long)yy * X + clampi(first + lane + 64 * u, 0, X - 1)];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (lane + 64 * u < npos && l + h * NW < 64) tile[(lane + 64 * u) * LS + l + h * NW] = v[h][u];
+        }
+    }
+}
+
 // Long-kernel variant (radius up to 127, float32 volumes): every lane owns one line and slides along
 // the filter axis with register-resident left/right windows of R outputs, the line segment (tile +
 // 2*radius halo) staged once in LDS as float32.
@@ -68,21 +106,7 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
     const float *src = in + (long)z * Y * X;
     float *dst = out + (long)z * Y * X;
 
-    if (AXIS == 1) {
-        const int xx = min(l0 + lane, X - 1);
-        for (int p = wave; p < npos; p += 4) {
-            const int yy = clampi(p0 - r + p, 0, Y - 1);
-            tile[p * LS + lane] = src[(long)yy * X + xx];
-        }
-    } else {
-        for (int l = wave; l < 64; l += 4) {
-            const int yy = min(l0 + l, Y - 1);
-            for (int p = lane; p < npos; p += 64) {
-                const int xx = clampi(p0 - r + p, 0, X - 1);
-                tile[p * LS + l] = src[(long)yy * X + xx];
-            }
-        }
-    }
+    stage_tile<AXIS, 4>(tile, src, npos, p0 - r, l0, Y, X, lane, wave);
     __syncthreads();
 
     const int line = l0 + lane;
@@ -130,20 +154,20 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
     }
 }
 
-// ---- fast (NOT bit-exact) long pass for the certified argmax: float32 packed math, FMA allowed ---------------------------
-// Same tiling as k_corr_long_f32; every lane slides two adjacent 8-output groups packed as float2 so that the
-// compiler emits v_pk_add_f32 / v_pk_fma_f32 (2 instructions per tap pair for 2 outputs instead of 6 double ones).
+// ---- fast (NOT bit-exact) long pass for the certified argmax: float32 math, FMA allowed -----------------------------------
+// Same tiling as k_corr_long_f32; every lane slides R outputs with float32 left/right register windows:
+//     acc[i] = fma(L[i] + Rr[i], w[d], acc[i])        -> one v_add_f32 + one v_fma_f32 per output and tap
+// (measured on gfx950: scalar v_fma_f32 issues at twice the rate of v_pk_fma_f32, so packing buys nothing and the
+// odd/even pair shuffles it needs cost as much as the arithmetic).  The tap loop is unrolled R times so the window
+// rotation is pure register renaming; per tap a wave reads 2 window words + 1 broadcast tap from LDS for R outputs.
 // Error vs the exact pass: every term is non-negative, so |fast - exact| <= ((1+u)^(r+3) - 1) * exact, u = 2^-24
 // (tap rounding + pair-sum rounding + at most r+1 FMA roundings); see k_argmax_certify for how the bound is used.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int AXIS, int TO, int NW>
+template <int AXIS, int TO, int NW, int R>
 __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X,
                                                         TapsF taps)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     constexpr int LS = AXIS == 1 ? 64 : 65;
-    constexpr int R = 8;
     const int r = taps.n >> 1;
     const int npos = TO + 2 * r;
     const int lane = threadIdx.x & 63;
@@ -155,67 +179,64 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
     const int l0 = blockIdx.x * 64;
     const float *src = in + (long)z * Y * X;
     float *dst = out + (long)z * Y * X;
-    if (AXIS == 1) {
-        const int xx = min(l0 + lane, X - 1);
-        for (int p = wave; p < npos; p += NW) {
-            const int yy = clampi(p0 - r + p, 0, Y - 1);
-            tile[p * LS + lane] = src[(long)yy * X + xx];
-        }
-    } else {
-        for (int l = wave; l < 64; l += NW) {
-            const int yy = min(l0 + l, Y - 1);
-            for (int p = lane; p < npos; p += 64) {
-                const int xx = clampi(p0 - r + p, 0, X - 1);
-                tile[p * LS + l] = src[(long)yy * X + xx];
-            }
-        }
-    }
+    // taps live in LDS: scalar loads in the tap loop would share lgkmcnt with the window reads and force a full
+    // drain (s_waitcnt lgkmcnt(0)) at every use; LDS broadcasts return in order and pipeline with them
+    __shared__ __attribute__((aligned(16))) float wl[256];
+    for (int i = threadIdx.x; i < 256; i += NW * 64) wl[i] = taps.w[i];
+    stage_tile<AXIS, NW>(tile, src, npos, p0 - r, l0, Y, X, lane, wave);
     __syncthreads();
     const int line = l0 + lane;
     constexpr int PER_WAVE = TO / NW;
+    static_assert(PER_WAVE % R == 0, "outputs per wave must be a multiple of the group size");
+    constexpr bool STAGED = AXIS == 2 && PER_WAVE == R;  // x pass: results go back through LDS for coalesced row stores
     for (int g = 0; g < PER_WAVE / R; ++g) {
         const int o0 = wave * PER_WAVE + g * R;
-        if (p0 + o0 >= len) break;
+        const bool active = p0 + o0 < len;  // wave-uniform
+        if (!STAGED && !active) break;
         const float *ctr = tile + (r + o0) * LS + lane;
-        // 8 outputs as 4 packed pairs (o, o+1).  Tap d uses "even" windows, tap d-1 "odd" windows (shifted by one
-        // position); both shift by a whole pair every two taps, so after 8 taps every register has been renewed and the
-        // unrolled loop needs no moves.  r must be even (120 for sigma 30).
-        const float wc = taps.w[r];
-        f32x2 acc[4], EL[4], OL[4], ER[4], OR[4];
+        float acc[R], L[R], Rr[R];
+        if (active) {
+            const float wc = wl[r];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] = f32x2{ctr[(2 * i) * LS], ctr[(2 * i + 1) * LS]} * wc;
-            EL[i] = f32x2{ctr[(2 * i - r) * LS], ctr[(2 * i + 1 - r) * LS]};
-            OL[i] = f32x2{ctr[(2 * i + 1 - r) * LS], ctr[(2 * i + 2 - r) * LS]};
-            ER[i] = f32x2{ctr[(2 * i + r) * LS], ctr[(2 * i + 1 + r) * LS]};
-            OR[i] = f32x2{ctr[(2 * i + r - 1) * LS], ctr[(2 * i + r) * LS]};
+            for (int i = 0; i < R; ++i) {
+                acc[i] = ctr[i * LS] * wc;
+                L[i] = ctr[(i - r) * LS];
+                Rr[i] = ctr[(i + r) * LS];
+            }
+#pragma unroll R
+            for (int d = r; d >= 1; --d) {
+                const float w = wl[r - d];
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(L[i] + Rr[i], w, acc[i]);
+#pragma unroll
+                for (int i = 0; i < R - 1; ++i) L[i] = L[i + 1];
+                L[R - 1] = ctr[(R - d) * LS];
+#pragma unroll
+                for (int i = R - 1; i > 0; --i) Rr[i] = Rr[i - 1];
+                Rr[0] = ctr[(d - 1) * LS];
+            }
         }
-#pragma unroll 4
-        for (int d = r; d >= 2; d -= 2) {
-            const float w0 = taps.w[r - d], w1 = taps.w[r - d + 1];
+        if (STAGED) {
+            constexpr int OS = TO + 1;  // odd row stride: lane-major writes and row-major reads are both conflict-free
+            __syncthreads();            // every wave has finished reading the input tile
+            if (active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(EL[i] + ER[i], f32x2{w0, w0}, acc[i]);
+                for (int i = 0; i < R; ++i) tile[lane * OS + o0 + i] = acc[i];
+            }
+            __syncthreads();
+            for (int l = wave; l < 64; l += NW) {
+                const int yy = l0 + l;
+                if (yy >= Y) break;
+                for (int p = lane; p < TO; p += 64)
+                    if (p0 + p < X) dst[(long)yy * X + p0 + p] = tile[l * OS + p];
+            }
+        } else if (line < nlines) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(OL[i] + OR[i], f32x2{w1, w1}, acc[i]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { EL[i] = EL[i + 1]; OL[i] = OL[i + 1]; }
-            EL[3] = f32x2{ctr[(8 - d) * LS], ctr[(9 - d) * LS]};
-            OL[3] = f32x2{ctr[(9 - d) * LS], ctr[(10 - d) * LS]};
-#pragma unroll
-            for (int i = 3; i > 0; --i) { ER[i] = ER[i - 1]; OR[i] = OR[i - 1]; }
-            ER[0] = f32x2{ctr[(d - 2) * LS], ctr[(d - 1) * LS]};
-            OR[0] = f32x2{ctr[(d - 3) * LS], ctr[(d - 2) * LS]};
-        }
-        if (line < nlines) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pp = p0 + o0 + 2 * i + h;
-                    const float val = h == 0 ? acc[i].x : acc[i].y;
-                    if (AXIS == 1) { if (pp < Y) dst[(long)pp * X + line] = val; }
-                    else { if (pp < X) dst[(long)line * X + pp] = val; }
-                }
+            for (int i = 0; i < R; ++i) {
+                const int pp = p0 + o0 + i;
+                if (AXIS == 1) { if (pp < Y) dst[(long)pp * X + line] = acc[i]; }
+                else { if (pp < X) dst[(long)line * X + pp] = acc[i]; }
+            }
         }
     }
 }

@@ -12,6 +12,7 @@
 
 namespace tip {
 
+
 int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
 
 struct ClipInfo {
@@ -344,6 +345,39 @@ __global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restri
                 if (x0 + k < X) proj[(long)c * P + (long)y * X + x0 + k] = (double)mx[c][k];
 }
 
+// (waves per block) * 100 + (outputs per lane and group) of the fast sigma-30 passes; see k_corr_long_fast
+#ifndef FAST_CFG_Y
+#define FAST_CFG_Y 1616
+#endif
+#ifndef FAST_CFG_X
+#define FAST_CFG_X 1616
+#endif
+
+template <int AXIS, int NW, int R>
+static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
+{
+    const int r = t.n >> 1;
+    const size_t lds = (size_t)(256 + 2 * r) * (AXIS == 1 ? 64 : 65) * sizeof(float);
+    auto k = k_corr_long_fast<AXIS, 256, NW, R>;
+    TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid = AXIS == 1 ? dim3(cdiv(X, 64), cdiv(Y, 256), Zs) : dim3(cdiv(Y, 64), cdiv(X, 256), Zs);
+    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(NW * 64), lds, in, out, Zs, Y, X, t);
+    return TIP_OK;
+}
+
+template <int AXIS>
+static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
+{
+    switch (cfg) {
+    case 1608: return launch_fast_cfg<AXIS, 16, 8>(in, out, Zs, Y, X, t);
+    case 1616: return launch_fast_cfg<AXIS, 16, 16>(in, out, Zs, Y, X, t);
+    case 816: return launch_fast_cfg<AXIS, 8, 16>(in, out, Zs, Y, X, t);
+    case 832: return launch_fast_cfg<AXIS, 8, 32>(in, out, Zs, Y, X, t);
+    case 432: return launch_fast_cfg<AXIS, 4, 32>(in, out, Zs, Y, X, t);
+    default: return fail(TIP_ERR_ARG, "unknown fast-pass configuration %d", cfg);
+    }
+}
+
 // ---- certified argmax --------------------------------------------------------------------------------------------------
 // The sigma-30 score is used for ONE thing: chosen_z = argmax_z(score) (sp.py:55-61).  So the score itself need not be
 // exact -- only the argmax must be.  The fast passes (k_corr_long_fast) give S~ with |S~ - S| <= EPS * S for the exact
@@ -519,14 +553,10 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         for (int i = 0; i < 256; ++i) f30.w[i] = (float)k30.w[i];
         const int r = k30.n >> 1;
         {   // fast y pass B -> A, fast x pass A -> D   (B, the exact z-passed volume, is kept for the exact fix-up)
-            size_t lds = (size_t)(256 + 2 * r) * 64 * sizeof(float);
-            auto ky = k_corr_long_fast<1, 256, 16>;
-            TIP_HIP(hipFuncSetAttribute((const void *)ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            TIP_LAUNCH("score_fast_y", ky, dim3(cdiv(X, 64), cdiv(Y, 256), Zs), dim3(1024), lds, (const float *)B, A, Zs, Y, X, f30);
-            lds = (size_t)(256 + 2 * r) * 65 * sizeof(float);
-            auto kx = k_corr_long_fast<2, 256, 16>;
-            TIP_HIP(hipFuncSetAttribute((const void *)kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            TIP_LAUNCH("score_fast_x", kx, dim3(cdiv(Y, 64), cdiv(X, 256), Zs), dim3(1024), lds, (const float *)A, D, Zs, Y, X, f30);
+            int cy = FAST_CFG_Y, cx = FAST_CFG_X;
+            if (const char *e = getenv("TIP_FAST_CFG")) sscanf(e, "%d,%d", &cy, &cx);  // tuning hook: NW*100+NP per pass
+            if ((rc = launch_fast<1>(cy, (const float *)B, A, Zs, Y, X, f30))) return rc;
+            if ((rc = launch_fast<2>(cx, (const float *)A, D, Zs, Y, X, f30))) return rc;
         }
         TIP_HIP(hipMemsetAsync(uncn, 0, sizeof(int), c.stream));
         TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(P, 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
