@@ -52,36 +52,67 @@ struct WsInfo {           // device-resident scalars
     int ties;                        // equal-valued non-marker neighbours exist
     int n_markers;
     int changed, undecided;          // per-iteration counters (mode A) / frontier, pending (mode B)
+    int unfinished, pad_;            // endgame: components whose replay hit the step limit
     unsigned long long fb_v, fb_k;   // fallback reduction
     unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
 };
 
+// Both reductions: 4 independent loads per thread and trip, one atomic per BLOCK (thousands of same-address 64-bit
+// atomics serialise in L2 and used to cost more than the 32 MB read itself).
+constexpr int WS_RED_BLOCKS = 512;
+
 __global__ void __launch_bounds__(256) k_ws_minmax(const double *__restrict__ v, long n, WsInfo *info)
 {
+    __shared__ unsigned long long slo[4], shi[4];
     unsigned long long lo = ~0ULL, hi = 0ULL;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const unsigned long long e = enc_f64(v[i]);
-        lo = e < lo ? e : lo;
-        hi = e > hi ? e : hi;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
+        unsigned long long e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = i + u * stride < n ? enc_f64(v[i + u * stride]) : enc_f64(v[i]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo = e[u] < lo ? e[u] : lo;
+            hi = e[u] > hi ? e[u] : hi;
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&info->emin, lo); atomicMax(&info->emax, hi); }
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = slo[w] < lo ? slo[w] : lo;
+            hi = shi[w] > hi ? shi[w] : hi;
+        }
+        atomicMin(&info->emin, lo);
+        atomicMax(&info->emax, hi);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_ws_count_other(const double *__restrict__ v, long n, WsInfo *info)
 {
+    __shared__ unsigned long long sc[4];
     const unsigned long long emin = info->emin, emax = info->emax;
     unsigned long long c = 0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const unsigned long long e = enc_f64(v[i]);
-        c += (e != emin && e != emax);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
+        unsigned long long e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = i + u * stride < n ? enc_f64(v[i + u * stride]) : emin;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (e[u] != emin && e[u] != emax);
     }
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&info->n_other, c);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = sc[0] + sc[1] + sc[2] + sc[3];
+        if (c) atomicAdd(&info->n_other, c);
+    }
 }
 
 // ---- markers: label(local_minima(image)) ---------------------------------------------------------------------------
@@ -146,6 +177,8 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 constexpr int WT_FAST = 16, WTH_FAST = 64, WH_FAST = 3, WK_FAST = 6;
 constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 constexpr int LINE_LAB = -1;
+// tile-local marker "undecided and already on the work list": label 0 with a non-zero reference field (never leaves LDS)
+constexpr unsigned long long ST_LISTED = 1ULL << 32;
 
 struct T2 { double v; int i; };
 __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
@@ -153,47 +186,59 @@ __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.
 struct TileView {
     const double *sv;                  // LDS: image values of the window
     const unsigned long long *sst;     // LDS: packed state (label | pop-time reference pixel << 32)
-    const int *sgi;                    // LDS: global linear index of every window cell
     const double *gv;                  // global image (pop-time value of pulled pixels = gv[tref])
     unsigned short *vis;               // LDS: this thread's pocket list
     int budget;                        // pocket flood budget (cells)
     int WL;                            // window edge (tile + 2 * halo)
-    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], sgi[c]}; }
+    int g00, X;                        // global linear index of window cell 0 (may be negative), image row length
+    // global linear index of window cell c (meaningless for cells outside the image: those are LINE and never compared)
+    __device__ __forceinline__ int gi(int c) const { const int cy = c / WL; return g00 + cy * X + (c - cy * WL); }
+    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], gi(c)}; }
     __device__ __forceinline__ T2 Tof(int c, unsigned long long s) const
     {
         const int tr = st_tref(s);
-        return T2{tr == sgi[c] ? sv[c] : gv[tr], tr};
+        return T2{tr == gi(c) ? sv[c] : gv[tr], tr};
     }
 };
 
 // Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
 // key < t around q (breadth first, the per-thread list in LDS is queue and visited set at once); the pocket is closed
 // iff nothing labelled before t touches it.  Running out of budget or window is "cannot certify" (the pixel waits).
-__device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, double tvv, int tii)
+// Out of line to keep the everyday rule small -- so everything it needs travels BY VALUE in registers, with the LDS
+// arrays as address-space-3 pointers: a TileView reference would live on the (global-memory) stack and every field
+// access in the flood would be a scratch load (measured: a certificate round cost 400k cycles that way).
+typedef __attribute__((address_space(3))) const double *lds_cf64;
+typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
+typedef __attribute__((address_space(3))) unsigned short *lds_u16;
+
+__device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, const double *__restrict__ gv, int budget, int WL,
+                                     int g00, int X, int q, int asker, double tvv, int tii)
 {
     const T2 t{tvv, tii};
     int nv = 1, head = 0;
-    const int WL = tv.WL;
-    tv.vis[0] = (unsigned short)q;
+    vis[0] = (unsigned short)q;
     while (head < nv) {
-        const int c = tv.vis[head++];
+        const int c = vis[head++];
         const int cy = c / WL, cx = c - cy * WL;
         if (cy == 0 || cy == WL - 1 || cx == 0 || cx == WL - 1) return false;  // neighbours outside the window
+        const int gc = g00 + cy * X + cx;
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             const int m = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
             if (m == asker) continue;
-            const unsigned long long sm = tv.sst[m];
+            const int gm = k == 0 ? gc - X : (k == 1 ? gc - 1 : (k == 2 ? gc + 1 : gc + X));
+            const unsigned long long sm = sst[m];
             const int l = st_lab(sm);
             if (l == LINE_LAB) continue;
             if (l > 0) {
-                if (t_lt(tv.Tof(m, sm), t)) return false;
-            } else if (t_lt(tv.key(m), t)) {
+                const int tr = st_tref(sm);
+                if (t_lt(T2{tr == gm ? sv[m] : gv[tr], tr}, t)) return false;
+            } else if (t_lt(T2{sv[m], gm}, t)) {
                 bool seen = false;
-                for (int j = 0; j < nv; ++j) seen |= tv.vis[j] == (unsigned short)m;
+                for (int j = 0; j < nv; ++j) seen |= vis[j] == (unsigned short)m;
                 if (!seen) {
-                    if (nv >= tv.budget) return false;
-                    tv.vis[nv++] = (unsigned short)m;
+                    if (nv >= budget) return false;
+                    vis[nv++] = (unsigned short)m;
                 }
             }
         }
@@ -201,12 +246,17 @@ __device__ __noinline__ bool ws_cert(const TileView &tv, int q, int asker, doubl
     return true;
 }
 
+__device__ __forceinline__ bool ws_cert(const TileView &tv, int q, int asker, double tvv, int tii)
+{
+    return ws_cert((lds_cf64)tv.sv, (lds_cu64)tv.sst, (lds_u16)tv.vis, tv.gv, tv.budget, tv.WL, tv.g00, tv.X, q, asker, tvv, tii);
+}
+
 struct Decision { int lab; int ti; };  // lab == 0: no decision; ti = pop-time reference pixel
 
 // The flood rule for one undecided cell, written for few instructions: all LDS loads first, then predicated
 // arithmetic; the pocket certificates (rare) are the only calls.  certs == false: any undecided neighbour that could
 // pop earlier makes the pixel wait (the common case: that neighbour is simply not processed yet).
-__device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool certs)
+__device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc, bool certs)
 {
     Decision d{0, 0};
     const int WL = tv.WL;
@@ -215,7 +265,7 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, bool ce
     const int l0 = st_lab(s0), l1 = st_lab(s1), l2 = st_lab(s2), l3 = st_lab(s3);
     if (!(l0 > 0 || l1 > 0 || l2 > 0 || l3 > 0)) return d;
     const double v0 = tv.sv[q0], v1 = tv.sv[q1], v2 = tv.sv[q2], v3 = tv.sv[q3], vc = tv.sv[c];
-    const int g0 = tv.sgi[q0], g1 = tv.sgi[q1], g2 = tv.sgi[q2], g3 = tv.sgi[q3], gc = tv.sgi[c];
+    const int g0 = gc - tv.X, g1 = gc - 1, g2 = gc + 1, g3 = gc + tv.X;
     int s_lab = 0, pull_lab = 0, pull_ti = 0;
     bool conflict = false, has_pull = false;
     double pull_tv = 0.0;
@@ -282,16 +332,14 @@ template <int WT, int WS_THREADS, int WH, int WK>
 __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
                                                   unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
-                                                  int first, int max_rounds, WsInfo *info)
+                                                  int *__restrict__ tile_front, int first, int max_rounds, int dbg, WsInfo *info)
 {
     constexpr int WL = WT + 2 * WH;
     __shared__ double sv[WL * WL];
     __shared__ unsigned long long sst[WL * WL];     // label | pop-time reference pixel << 32, one 8-byte word
-    __shared__ int sgi[WL * WL];
-    __shared__ int sinl[WL * WL];
     __shared__ unsigned short svis[WS_THREADS * WK];
     __shared__ unsigned short slist[2][WT * WT];
-    __shared__ int s_n[2], s_any, s_und, s_chg;
+    __shared__ int s_n[2], s_any, s_und, s_chg, s_front;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
     if (first == 2 && tile_und[tile] == 0) return;  // wide pass: every tile that still has undecided pixels
     if (!first) {
@@ -305,29 +353,44 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         if (!act) return;
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
-    for (int c = threadIdx.x; c < WL * WL; c += WS_THREADS) {
-        const int ly = c / WL, lx = c - ly * WL;
-        const int gy = gy0 + ly, gx = gx0 + lx;
-        sinl[c] = 0;
-        if (gy < 0 || gy >= Y || gx < 0 || gx >= X) {
-            sst[c] = pack_st(LINE_LAB, 0); sv[c] = 0.0; sgi[c] = -1;
-        } else {
-            const int gi = gy * X + gx;
-            sv[c] = v[gi]; sst[c] = st[gi]; sgi[c] = gi;
+    {   // window load: every global load of the thread is issued before the first LDS write (one wave per tile and few
+        // tiles per CU: nothing else hides the latency)
+        constexpr int NLOAD = (WL * WL + WS_THREADS - 1) / WS_THREADS;
+        double lv[NLOAD];
+        unsigned long long ls[NLOAD];
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            const int c = threadIdx.x + u * WS_THREADS;
+            const int ly = c / WL, lx = c - ly * WL;
+            const int gy = gy0 + ly, gx = gx0 + lx;
+            const bool in = c < WL * WL && gy >= 0 && gy < Y && gx >= 0 && gx < X;
+            const int gi = in ? gy * X + gx : 0;
+            lv[u] = v[gi];
+            ls[u] = st[gi];
+            if (!in) { lv[u] = 0.0; ls[u] = pack_st(LINE_LAB, 0); }
+        }
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            const int c = threadIdx.x + u * WS_THREADS;
+            if (c < WL * WL) { sv[c] = lv[u]; sst[c] = ls[u]; }
         }
     }
-    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; }
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; s_front = 0; }
     __syncthreads();
-    TileView tv{sv, sst, sgi, v, svis + threadIdx.x * WK, WK, WL};
+    const int g00 = gy0 * X + gx0;
+    TileView tv{sv, sst, v, svis + threadIdx.x * WK, WK, WL, g00, X};
     // initial frontier: undecided interior cells next to a labelled cell
-#pragma unroll 1
+    unsigned was_und = 0;   // bit k: own interior cell k was undecided when the window was loaded
+#pragma unroll
     for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
-        if (st_lab(sst[c]) == 0 && (st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 ||
-                                    st_lab(sst[c + WL]) > 0)) {
-            sinl[c] = 1;
-            slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
+        if (st_lab(sst[c]) == 0) {
+            was_und |= 1u << k;
+            if (st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 || st_lab(sst[c + WL]) > 0) {
+                sst[c] = ST_LISTED;
+                slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
+            }
         }
     }
     __syncthreads();
@@ -347,7 +410,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             dec[j].lab = 0; dec[j].ti = 0;
             if (i < n) {
                 const int c = slist[cur][i];
-                if (st_lab(sst[c]) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, certs); }
+                if (st_lab(sst[c]) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
                 // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
             }
         }
@@ -362,7 +425,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
                 continue;
             }
-            sst[c] = pack_st(dec[j].lab, dec[j].ti); sinl[c] = 0;
+            sst[c] = pack_st(dec[j].lab, dec[j].ti);
             s_any = 1;
             atomicAdd(&s_chg, 1);
             if (dec[j].lab > 0) {
@@ -370,7 +433,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 for (int k = 0; k < 4; ++k) {
                     const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
                     const int qy = q / WL, qx = q - qy * WL;
-                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && st_lab(sst[q]) == 0 && atomicExch(&sinl[q], 1) == 0)
+                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && atomicCAS(&sst[q], 0ULL, ST_LISTED) == 0ULL)
                         slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
                 }
             }
@@ -379,32 +442,41 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         cur ^= 1;
         if (s_any) { certs = false; continue; }
         if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
-        certs = true;       // local stall: one round with pocket certificates
+        // local stall.  Pocket certificates cost ~40 plain rounds, and a tile that has just moved is re-run next launch
+        // anyway (with its neighbours' news): only a tile that got nowhere at all tries them.
+        if (s_chg > 0) break;
+        certs = true;
     }
     __syncthreads();
-    int und = 0;
-#pragma unroll 1
+    // und: undecided cells left; front: those of them that touch a labelled cell.  When no tile changed any more and
+    // the frontier is empty everywhere, the serial flood's heap would be empty too: the rest stays 0.
+    int und = 0, front = 0;
+#pragma unroll
     for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
+        if (!((was_und >> k) & 1u)) continue;   // decided before this launch (cells outside the image are LINE)
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
-        const int gi = sgi[c];
-        if (gi >= 0) {
-            const unsigned long long sc = sst[c];
-            if (st_lab(sc) == 0) und++;
-            else if (st_lab(st[gi]) == 0) st[gi] = sc;
+        const unsigned long long sc = sst[c];
+        if (st_lab(sc) == 0) {
+            und++;
+            front += st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 || st_lab(sst[c + WL]) > 0;
+        } else {
+            st[(ty * WT + p / WT) * X + tx * WT + p % WT] = sc;   // only this tile writes its interior
         }
     }
-    if (und) atomicAdd(&s_und, und);
+    if (und) { atomicAdd(&s_und, und); atomicAdd(&s_front, front); }
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_und[tile] = s_und;
+        tile_front[tile] = s_front;
         changed_cur[tile] = s_chg > 0;
         if (s_chg > 0) atomicAdd(&info->changed, s_chg);
-        if (s_und) atomicAdd(&info->undecided, s_und);
-        atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
-        atomicAdd(&info->dbg_tiles, 1ULL);
+        if (dbg) {
+            atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
+            atomicAdd(&info->dbg_tiles, 1ULL);
+        }
     }
-    if (my_evals) atomicAdd(&info->dbg_evals, (unsigned long long)my_evals);
+    if (dbg && my_evals) atomicAdd(&info->dbg_evals, (unsigned long long)my_evals);
 }
 
 // fallback: the undecided pixel with the globally smallest pop time is always safe to commit
@@ -481,7 +553,9 @@ __global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long 
 // wait for them.  Connected components of undecided pixels evolve independently (everything around them is final), so
 // each one is finished by ONE wave running the serial rule -- commit the component's smallest pop time, repeat -- on an
 // LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / global-minimum fallback.
-constexpr int END_CAP = 1024;
+constexpr int END_CAP = 512;
+constexpr int WS_EARLY_BURST = 2;   // the first endgame runs after this many tile bursts, without waiting for a stall
+constexpr int WS_END_STEPS = 32;    // serial commits per component and endgame: clears the stuck seeds, the rest is tile work
 
 struct SameU {
     const unsigned long long *st;
@@ -515,11 +589,19 @@ __global__ void __launch_bounds__(256) k_end_scatter(const unsigned long long *_
     if (isroot[i]) roots[rootrank[i]] = (int)i;
 }
 
+// One wave replays the serial flood on one component.  Every cell caches its candidate pop time
+//     cand = max(own key, earliest pop time among its labelled neighbours)          (none while it has no labelled one)
+// as a sortable 128-bit key (encoded value | reference pixel, own pixel) in the REGISTERS of its owner lane (cell k ->
+// lane k % 64, slot k / 64).  Pop times only grow, so a commit can only GIVE a candidate to neighbours that had none: a
+// step is a register scan + wave-wide minimum, the flood rule for the winner (all lanes redundantly: the LDS reads
+// are broadcasts) and at most four candidate updates.
 __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                     const int *__restrict__ roots, const int *__restrict__ cnt,
                                                     const int *__restrict__ off, const int *__restrict__ cells,
                                                     const int *__restrict__ slot, int max_steps, WsInfo *info)
 {
+    constexpr int EPL = END_CAP / 64;       // cells per lane
+    constexpr unsigned long long NONE = ~0ULL;
     __shared__ double cv[END_CAP];          // value of the cell
     __shared__ int cgi[END_CAP];            // global index
     __shared__ int clab[END_CAP], ctr[END_CAP];   // state: label / 0 / LINE and pop-time reference
@@ -532,81 +614,104 @@ __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v
     if (m > END_CAP) { if (threadIdx.x == 0) atomicAdd(&info->undecided, m); return; }
     const int base = off[r];
     const int lane = threadIdx.x;
-    for (int k = lane; k < m; k += 64) {
+    // candidate keys: hi = encoded pop-time value (NONE: not a candidate), lo = reference pixel << 32 | own pixel
+    // (hi == NONE: lo == 0 "no labelled neighbour yet", lo == 1 "committed")
+    unsigned long long ch[EPL], cl[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) {
+        ch[u] = NONE; cl[u] = 1;
+        const int k = lane + 64 * u;
+        if (k >= m) continue;
         const int gi = cells[base + k];
         const int y = gi / X, x = gi - y * X;
-        cv[k] = v[gi]; cgi[k] = gi; clab[k] = 0; ctr[k] = 0;
+        const double kv = v[gi];
+        cv[k] = kv; cgi[k] = gi; clab[k] = 0; ctr[k] = 0;
         const int nb[4] = {y > 0 ? gi - X : -1, x > 0 ? gi - 1 : -1, x < X - 1 ? gi + 1 : -1, y < Y - 1 ? gi + X : -1};
+        bool has = false; double tv = 0.0; int ti = 0;
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             int code = -1;
             if (nb[j] >= 0) {
-                const unsigned long long s = st[nb[j]];
-                const int l = st_lab(s);
+                const unsigned long long sq = st[nb[j]];
+                const int l = st_lab(sq);
                 if (l == 0) code = slot[nb[j]];
                 else if (l > 0) {
-                    const int tr = st_tref(s);
-                    code = -2; elab[j][k] = l; etr[j][k] = tr; ev[j][k] = v[tr];
+                    const int tr = st_tref(sq);
+                    const double qv = v[tr];
+                    code = -2; elab[j][k] = l; etr[j][k] = tr; ev[j][k] = qv;
+                    if (!has || qv < tv || (qv == tv && tr < ti)) { tv = qv; ti = tr; has = true; }
                 }
             }
             cnb[j][k] = code;
         }
+        // pop time = max(own key, earliest labelled neighbour)
+        double pv = kv; int pi = gi;
+        if (has && (tv > pv || (tv == pv && ti > pi))) { pv = tv; pi = ti; }
+        cl[u] = 0;
+        if (has) { ch[u] = enc_f64(pv + 0.0); cl[u] = ((unsigned long long)(unsigned)pi << 32) | (unsigned)gi; }
     }
     __syncthreads();
     int committed = 0;
-    // only the first max_steps commits are serial: that clears the stuck seeds; their dependents are ordinary pixels
-    // again and go back to the (parallel) tile rounds
     for (int step = 0; step < max_steps; ++step) {
-        // every lane: best (smallest pop time) among its undecided cells that touch a labelled cell
-        double bv = 0.0; int bi = 0, bk = -1;
-        for (int k = lane; k < m; k += 64) {
-            if (clab[k] != 0) continue;
-            bool has = false; double tv = 0.0; int ti = 0;
-            for (int j = 0; j < 4; ++j) {
-                const int code = cnb[j][k];
-                double qv; int qi;
-                if (code == -2) { qv = ev[j][k]; qi = etr[j][k]; }
-                else if (code >= 0 && clab[code] > 0) { const int tr = ctr[code]; qi = tr; qv = tr == cgi[code] ? cv[code] : v[tr]; }
-                else continue;
-                if (!has || qv < tv || (qv == tv && qi < ti)) { tv = qv; ti = qi; has = true; }
-            }
-            if (!has) continue;
-            // pop time = max(own key, earliest labelled neighbour)
-            double pv = cv[k]; int pi = cgi[k];
-            if (tv > pv || (tv == pv && ti > pi)) { pv = tv; pi = ti; }
-            if (bk < 0 || pv < bv || (pv == bv && (pi < bi || (pi == bi && cgi[k] < cgi[bk])))) { bv = pv; bi = pi; bk = k; }
-        }
-        // wave minimum over (bv, bi, cgi[bk])
-        int bg = bk >= 0 ? cgi[bk] : 0x7fffffff;
+        // lane-local best, then wave minimum
+        unsigned long long bh = ch[0], bl = cl[0];
+        int bu = 0;
+#pragma unroll
+        for (int u = 1; u < EPL; ++u)
+            if (ch[u] < bh || (ch[u] == bh && cl[u] < bl)) { bh = ch[u]; bl = cl[u]; bu = u; }
+        const unsigned long long mh = bh, ml = bl;
         for (int d = 32; d >= 1; d >>= 1) {
-            const double ov = __shfl_xor(bv, d, 64);
-            const int oi = __shfl_xor(bi, d, 64), ok = __shfl_xor(bk, d, 64), og = __shfl_xor(bg, d, 64);
-            const bool take = ok >= 0 && (bk < 0 || ov < bv || (ov == bv && (oi < bi || (oi == bi && og < bg))));
-            if (take) { bv = ov; bi = oi; bk = ok; bg = og; }
+            const unsigned long long oh = __shfl_xor(bh, d, 64), ol = __shfl_xor(bl, d, 64);
+            if (oh < bh || (oh == bh && ol < bl)) { bh = oh; bl = ol; }
         }
-        if (bk < 0) break;  // nothing reachable is left (wave-uniform)
-        if (lane == 0) {
-            const int k = bk;
-            const double kv = cv[k]; const int ki = cgi[k];
-            int s_lab = 0, pull_lab = 0, pull_tr = 0; bool conflict = false, has_pull = false; double pt = 0.0; int pti = 0;
-            for (int j = 0; j < 4; ++j) {
-                const int code = cnb[j][k];
-                double qv; int qi, ql;
-                if (code == -2) { qv = ev[j][k]; qi = etr[j][k]; ql = elab[j][k]; }
-                else if (code >= 0 && clab[code] > 0) { const int tr = ctr[code]; qi = tr; qv = tr == cgi[code] ? cv[code] : v[tr]; ql = clab[code]; }
-                else continue;
-                if (qv < kv || (qv == kv && qi < ki)) {
-                    if (s_lab == 0) s_lab = ql; else if (s_lab != ql) conflict = true;
-                } else if (!has_pull || qv < pt || (qv == pt && qi < pti)) { has_pull = true; pt = qv; pti = qi; pull_lab = ql; pull_tr = qi; }
-            }
-            if (s_lab != 0) { clab[k] = conflict ? LINE_LAB : s_lab; ctr[k] = ki; }
-            else { clab[k] = pull_lab; ctr[k] = pull_tr; }
+        if (bh == NONE) break;  // nothing reachable is left (wave-uniform)
+        const int wl = __ffsll((unsigned long long)__ballot(mh == bh && ml == bl)) - 1;   // unique: lo holds the own pixel
+        const int k = wl + 64 * __shfl(bu, wl, 64);
+        const int bi = (int)(unsigned)(bl >> 32);    // the winner pops at (value bh, reference pixel bi)
+        // the flood rule for the winner (same on every lane)
+        const double kv = cv[k]; const int ki = cgi[k];
+        int s_lab = 0, pull_lab = 0, pull_tr = 0; bool conflict = false, has_pull = false; double pt = 0.0; int pti = 0;
+        int codes[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int code = cnb[j][k];
+            codes[j] = code;
+            double qv; int qi, ql;
+            if (code == -2) { qv = ev[j][k]; qi = etr[j][k]; ql = elab[j][k]; }
+            else if (code >= 0 && clab[code] > 0) { const int tr = ctr[code]; qi = tr; qv = tr == cgi[code] ? cv[code] : v[tr]; ql = clab[code]; }
+            else continue;
+            if (qv < kv || (qv == kv && qi < ki)) {
+                if (s_lab == 0) s_lab = ql; else if (s_lab != ql) conflict = true;
+            } else if (!has_pull || qv < pt || (qv == pt && qi < pti)) { has_pull = true; pt = qv; pti = qi; pull_lab = ql; pull_tr = qi; }
         }
+        const int new_lab = s_lab != 0 ? (conflict ? LINE_LAB : s_lab) : pull_lab;
+        const int new_tr = s_lab != 0 ? ki : pull_tr;
+        // a label (not a line) gives its still candidate-less neighbours a pop time: max(their key, (bh, bi))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int code = codes[j];
+            if (code < 0 || new_lab <= 0) continue;        // wave-uniform
+            const unsigned long long qh = enc_f64(cv[code] + 0.0);
+            const int qg = cgi[code];
+            const bool later = bh > qh || (bh == qh && bi > qg);
+            const unsigned long long nh = later ? bh : qh;
+            const unsigned long long nl = ((unsigned long long)(unsigned)(later ? bi : qg) << 32) | (unsigned)qg;
+            const int ol = code & 63, ou = code >> 6;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u)
+                if (lane == ol && u == ou && ch[u] == NONE && cl[u] == 0) { ch[u] = nh; cl[u] = nl; }
+        }
+#pragma unroll
+        for (int u = 0; u < EPL; ++u)
+            if (lane == wl && u == bu) { ch[u] = NONE; cl[u] = 1; }
+        if (lane == 0) { clab[k] = new_lab; ctr[k] = new_tr; }
         committed++;
         __syncthreads();
     }
     for (int k = lane; k < m; k += 64)
         if (clab[k] != 0) st[cgi[k]] = pack_st(clab[k], ctr[k]);
     if (lane == 0 && committed) atomicAdd(&info->changed, committed);
+    if (lane == 0 && committed == max_steps) atomicAdd(&info->unfinished, 1);   // (may have been finished exactly: harmless)
 }
 
 // ---- mode B: generation-synchronous BFS on a two-valued image --------------------------------------------------------
@@ -689,12 +794,12 @@ __global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__res
 __global__ void k_ws_info_init(WsInfo *info)
 {
     info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
-    info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
 }
 __global__ void k_ws_iter_reset(WsInfo *info)
 {
-    info->changed = 0; info->undecided = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
 }
 
@@ -713,8 +818,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     if (!info || !parent || !flag || !isroot || !rank || !st) return TIP_ERR_NOMEM;
     hipStream_t s = c.stream;
     TIP_LAUNCH("ws_info_init", k_ws_info_init, dim3(1), dim3(1), 0, info);
-    TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(min(1024, cdiv(n, 256))), dim3(256), 0, img, n, info);
-    TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(min(1024, cdiv(n, 256))), dim3(256), 0, img, n, info);
+    TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(min(WS_RED_BLOCKS, cdiv(n, 256))), dim3(256), 0, img, n, info);
+    TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(min(WS_RED_BLOCKS, cdiv(n, 256))), dim3(256), 0, img, n, info);
     // markers
     SameF64 same{img};
     int rc = uf_components(same, parent, Y, X);
@@ -759,16 +864,18 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         const int tilesX = cdiv(X, WT_FAST), tilesY = cdiv(Y, WT_FAST), ntiles = tilesX * tilesY;
         const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
         unsigned char *wchg = ws.get<unsigned char>((size_t)2 * wntiles);
-        int *wtile_und = ws.get<int>(wntiles);
+        int *wtile_und = ws.get<int>((size_t)2 * wntiles);
         if (!wchg || !wtile_und) return TIP_ERR_NOMEM;
         unsigned char *chg = ws.get<unsigned char>((size_t)2 * ntiles);
-        int *tile_und = ws.get<int>(ntiles);
+        int *tile_und = ws.get<int>((size_t)2 * ntiles);  // [0, ntiles) undecided cells per tile, [ntiles, 2 ntiles) its frontier
         if (!chg || !tile_und) return TIP_ERR_NOMEM;
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
         int iter = 0, fallbacks = 0;
         bool wide = false, wide_after_endgame = false;
         int endgames = 0;
         int burst_no = 0;
+        bool early_done = false;
+        const int dbg = getenv("TIP_WS_DEBUG") ? 1 : 0;
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             // tile launches go out in bursts with ONE host check per burst (a launch whose tiles are all inactive costs
@@ -781,10 +888,10 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
                 if (!wide)
                     TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y,
-                               X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, iter == 0 ? 1 : 0, 4096, info);
+                               X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, iter == 0 ? 1 : 0, 4096, dbg, info);
                 else {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
                     TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img,
-                               st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, 1, 4096, info);
+                               st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, wtile_und + wntiles, 1, 4096, dbg, info);
                     TIP_HIP(hipMemsetAsync(cur, 1, ntiles, s));
                 }
             }
@@ -793,17 +900,31 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             if (getenv("TIP_WS_DEBUG"))
                 fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d\n", iter, wide ? "wide" : "fast",
                         h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed);
-            if (h.changed > 0) { wide = false; continue; }
-            long und_total = 0;
+            // The first two bursts do the bulk; what is left then are a few thousand pixels in long dependency chains
+            // that would cost one (latency-bound) launch per tile border crossed: replay them serially per component
+            // right away instead of waiting for the tile rounds to stall.
+            // (measured on 2048^2 frames: after burst 2 with 32 serial steps per component 2.9 ms per frame; after burst 1
+            // 4.0 ms, after burst 3 3.05 ms, 512 steps 3.7 ms, no early endgame 3.6 ms)
+            const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !getenv("TIP_WS_NO_ENDGAME");
+            if (h.changed > 0 && !early_endgame) { wide = false; continue; }
+            const bool quiescent = h.changed == 0;
+            long und_total = 0, front_total = 0;
             {
-                std::vector<int> hu(ntiles);
-                TIP_HIP(hipMemcpyAsync(hu.data(), tile_und, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s));
+                std::vector<int> hu((size_t)2 * ntiles);
+                TIP_HIP(hipMemcpyAsync(hu.data(), tile_und, (size_t)2 * ntiles * 4, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
-                for (int v2 : hu) und_total += v2;
+                for (int t = 0; t < ntiles; ++t) {
+                    und_total += hu[t];
+                    if (hu[t]) front_total += hu[ntiles + t];
+                }
             }
             if (und_total == 0) break;
+            // quiescent and no undecided pixel touches a labelled one: what is left is enclosed by lines and stays 0.
+            // (After a wide pass the fine tiles' counts are stale, so this shortcut only applies to the fine rounds.)
+            if (front_total == 0 && !wide && quiescent) break;
             if (!wide_after_endgame && !getenv("TIP_WS_NO_ENDGAME")) {   // (env: test hook that exercises the fallback machinery)
-                // serial rule on every small connected component of undecided pixels (one wave each, bounded steps)
+                // serial rule on every connected component of undecided pixels that fits one wave's LDS copy
+                early_done = true;
                 SameU su{st};
                 if ((rc = uf_components(su, parent, Y, X))) return rc;
                 TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));      // cnt
@@ -825,17 +946,18 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
                 if (ncomp > 0)
                     TIP_LAUNCH("ws_end_resolve", k_end_resolve, dim3(ncomp), dim3(64), 0, img, st, Y, X, (const int *)roots,
-                               (const int *)flag, (const int *)off, (const int *)cellsbuf, (const int *)slot, 48, info);
+                               (const int *)flag, (const int *)off, (const int *)cellsbuf, (const int *)slot, WS_END_STEPS, info);
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
                 if (getenv("TIP_WS_DEBUG"))
-                    fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d\n", ncomp, h.changed, h.undecided);
+                    fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d, unfinished %d\n", ncomp, h.changed, h.undecided, h.unfinished);
                 endgames++;
-                if (h.changed > 0) {             // seeds cleared: back to the tile rounds (every tile with undecided pixels)
+                if (h.undecided == 0 && h.unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
+                if (h.changed > 0 || !quiescent) {   // oversize components remain: back to the tile rounds for them
                     TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+                    wide = false;
                     continue;
                 }
-                if (h.undecided == 0) break;     // nothing reachable is left: the rest stays 0, as in the serial flood
                 // only oversize components remain: wide pass / global-minimum fallback machinery
                 wide_after_endgame = true;
                 TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
