@@ -27,7 +27,6 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
     table = {
         "hist_u16": V * 2,
         "corr_z_u16clip": V * 2 + V * 4,
-        "corr_generic_z": 2 * V * 4, "corr_generic_y": 2 * V * 4, "corr_generic_x": 2 * V * 4,
         "corr_long_y": 2 * V * 4, "corr_long_x": 2 * V * 4,
         "score_fast_y": 2 * V * 4, "score_fast_x": 2 * V * 4,
         "zpass_u16clip_x4": V * 2 + V * 4, "zpass_f32_x4": 2 * V * 4, "ypass_slide_r4": 2 * V * 4, "xpass_slide_r4": 2 * V * 4,

@@ -184,9 +184,9 @@ struct T2 { double v; int i; };
 __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
 
 struct TileView {
-    const double *sv;                  // LDS: image values of the window
+    const double *sv;                  // LDS: undecided cell: its image value (= key value); labelled cell: its pop-time VALUE
+                                       // (its own value, or the puller's pop-time value for a pulled pixel)
     const unsigned long long *sst;     // LDS: packed state (label | pop-time reference pixel << 32)
-    const double *gv;                  // global image (pop-time value of pulled pixels = gv[tref])
     unsigned short *vis;               // LDS: this thread's pocket list
     int budget;                        // pocket flood budget (cells)
     int WL;                            // window edge (tile + 2 * halo)
@@ -194,11 +194,6 @@ struct TileView {
     // global linear index of window cell c (meaningless for cells outside the image: those are LINE and never compared)
     __device__ __forceinline__ int gi(int c) const { const int cy = c / WL; return g00 + cy * X + (c - cy * WL); }
     __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], gi(c)}; }
-    __device__ __forceinline__ T2 Tof(int c, unsigned long long s) const
-    {
-        const int tr = st_tref(s);
-        return T2{tr == gi(c) ? sv[c] : gv[tr], tr};
-    }
 };
 
 // Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
@@ -211,8 +206,8 @@ typedef __attribute__((address_space(3))) const double *lds_cf64;
 typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
 typedef __attribute__((address_space(3))) unsigned short *lds_u16;
 
-__device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, const double *__restrict__ gv, int budget, int WL,
-                                     int g00, int X, int q, int asker, double tvv, int tii)
+__device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, int budget, int WL, int g00, int X, int q, int asker,
+                                     double tvv, int tii)
 {
     const T2 t{tvv, tii};
     int nv = 1, head = 0;
@@ -231,8 +226,7 @@ __device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, 
             const int l = st_lab(sm);
             if (l == LINE_LAB) continue;
             if (l > 0) {
-                const int tr = st_tref(sm);
-                if (t_lt(T2{tr == gm ? sv[m] : gv[tr], tr}, t)) return false;
+                if (t_lt(T2{sv[m], st_tref(sm)}, t)) return false;
             } else if (t_lt(T2{sv[m], gm}, t)) {
                 bool seen = false;
                 for (int j = 0; j < nv; ++j) seen |= vis[j] == (unsigned short)m;
@@ -248,17 +242,17 @@ __device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, 
 
 __device__ __forceinline__ bool ws_cert(const TileView &tv, int q, int asker, double tvv, int tii)
 {
-    return ws_cert((lds_cf64)tv.sv, (lds_cu64)tv.sst, (lds_u16)tv.vis, tv.gv, tv.budget, tv.WL, tv.g00, tv.X, q, asker, tvv, tii);
+    return ws_cert((lds_cf64)tv.sv, (lds_cu64)tv.sst, (lds_u16)tv.vis, tv.budget, tv.WL, tv.g00, tv.X, q, asker, tvv, tii);
 }
 
-struct Decision { int lab; int ti; };  // lab == 0: no decision; ti = pop-time reference pixel
+struct Decision { int lab; int ti; double tv; };  // lab == 0: no decision; (tv, ti) = pop time: value and reference pixel
 
 // The flood rule for one undecided cell, written for few instructions: all LDS loads first, then predicated
 // arithmetic; the pocket certificates (rare) are the only calls.  certs == false: any undecided neighbour that could
 // pop earlier makes the pixel wait (the common case: that neighbour is simply not processed yet).
 __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc, bool certs)
 {
-    Decision d{0, 0};
+    Decision d{0, 0, 0.0};
     const int WL = tv.WL;
     const int q0 = c - WL, q1 = c - 1, q2 = c + 1, q3 = c + WL;
     const unsigned long long s0 = tv.sst[q0], s1 = tv.sst[q1], s2 = tv.sst[q2], s3 = tv.sst[q3];
@@ -278,10 +272,7 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
         double tq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
         if (l == LINE_LAB) continue;
         int ti = gq;
-        if (l > 0) {
-            ti = st_tref(sq);
-            if (ti != gq) tq = tv.gv[ti];   // pulled pixel: its pop time is another pixel's key (rare)
-        }
+        if (l > 0) ti = st_tref(sq);   // (tq already is the pop-time value of a labelled cell)
         const bool before = tq < vc || (tq == vc && ti < gc);
         if (l > 0) {
             if (before) {
@@ -306,7 +297,7 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
     }
     if (s_lab != 0) {
         d.lab = conflict ? LINE_LAB : s_lab;
-        d.ti = gc;
+        d.ti = gc; d.tv = vc;
         return d;
     }
     if (!has_pull) return d;
@@ -321,7 +312,7 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
         if (!certs) return d;
         if (!ws_cert(tv, q, c, pull_tv, pull_ti)) return d;
     }
-    d.lab = pull_lab; d.ti = pull_ti;
+    d.lab = pull_lab; d.ti = pull_ti; d.tv = pull_tv;
     return d;
 }
 
@@ -353,21 +344,26 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         if (!act) return;
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
-    {   // window load: every global load of the thread is issued before the first LDS write (one wave per tile and few
-        // tiles per CU: nothing else hides the latency)
+    {   // window load: all state loads of the thread in flight together, then all value loads (the value a labelled
+        // cell needs is its pop-time value v[tref]); one wave per tile and few tiles per CU: nothing else hides latency
         constexpr int NLOAD = (WL * WL + WS_THREADS - 1) / WS_THREADS;
-        double lv[NLOAD];
         unsigned long long ls[NLOAD];
+        double lv[NLOAD];
+        int lg[NLOAD];
 #pragma unroll
         for (int u = 0; u < NLOAD; ++u) {
             const int c = threadIdx.x + u * WS_THREADS;
             const int ly = c / WL, lx = c - ly * WL;
             const int gy = gy0 + ly, gx = gx0 + lx;
             const bool in = c < WL * WL && gy >= 0 && gy < Y && gx >= 0 && gx < X;
-            const int gi = in ? gy * X + gx : 0;
-            lv[u] = v[gi];
-            ls[u] = st[gi];
-            if (!in) { lv[u] = 0.0; ls[u] = pack_st(LINE_LAB, 0); }
+            lg[u] = in ? gy * X + gx : -1;
+            ls[u] = st[in ? lg[u] : 0];
+            if (!in) ls[u] = pack_st(LINE_LAB, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NLOAD; ++u) {
+            const int src = lg[u] < 0 ? 0 : (st_lab(ls[u]) > 0 ? st_tref(ls[u]) : lg[u]);
+            lv[u] = v[src];
         }
 #pragma unroll
         for (int u = 0; u < NLOAD; ++u) {
@@ -378,7 +374,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; s_front = 0; }
     __syncthreads();
     const int g00 = gy0 * X + gx0;
-    TileView tv{sv, sst, v, svis + threadIdx.x * WK, WK, WL, g00, X};
+    TileView tv{sv, sst, svis + threadIdx.x * WK, WK, WL, g00, X};
     // initial frontier: undecided interior cells next to a labelled cell
     unsigned was_und = 0;   // bit k: own interior cell k was undecided when the window was loaded
 #pragma unroll
@@ -407,7 +403,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         for (int j = 0; j < 4; ++j) {
             const int i = threadIdx.x + j * WS_THREADS;
             cc[j] = -1;
-            dec[j].lab = 0; dec[j].ti = 0;
+            dec[j].lab = 0; dec[j].ti = 0; dec[j].tv = 0.0;
             if (i < n) {
                 const int c = slist[cur][i];
                 if (st_lab(sst[c]) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
@@ -425,7 +421,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
                 continue;
             }
-            sst[c] = pack_st(dec[j].lab, dec[j].ti);
+            sst[c] = pack_st(dec[j].lab, dec[j].ti); sv[c] = dec[j].tv;
             s_any = 1;
             atomicAdd(&s_chg, 1);
             if (dec[j].lab > 0) {
