@@ -43,7 +43,7 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
     return table.get(kernel)
 
 
-PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r01d_pmc_traffic.json
+PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r*_pmc_traffic.json
     "ws_tiles": "k_ws_tiles<16, 64, 3, 6>", "score_fast_y": "k_corr_long_fast<1", "score_fast_x": "k_corr_long_fast<2",
     "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
     "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",
@@ -55,10 +55,12 @@ PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in separate
     runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     key = PMC_NAMES.get(kernel)
-    if not key or not os.path.exists(path):
+    if not key or not paths:
         return None
+    path = paths[-1]   # the latest committed set
     for name, rec in json.load(open(path)).items():
         if key in name:
             return (rec["fetch_MB_per_call_x2corrected"] + rec["write_MB_per_call"]) * 1e6
@@ -133,8 +135,8 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,6 +173,7 @@ def main():
     st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
     st_flip = np.ascontiguousarray(st[:, :, :, ::-1])
     nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else 1
+    steps_lock = threading.Lock()
 
     class Worker(object):
         """One frame in flight: own thread, own HIP stream / workspace pool (tip_init per thread), own resident buffers."""
@@ -200,8 +203,12 @@ def main():
                 if job is None:
                     return
                 kind, arg = job
-                if kind == "steps":
-                    for i in arg:
+                if kind == "steps":      # arg: shared iterator of step indices (workers pull, so no thread idles early)
+                    while True:
+                        with steps_lock:
+                            i = next(arg, None)
+                        if i is None:
+                            break
                         self.step(i)
                     self.pipe.sync()
                 elif kind == "prof":
@@ -234,8 +241,9 @@ def main():
     del st, st_flip
 
     def run_steps(n):
+        it = iter(range(n))
         for w in workers:
-            w.submit(("steps", list(range(w.wid, n, nthreads))))
+            w.submit(("steps", it))
         for w in workers:
             w.wait()
 
@@ -264,7 +272,7 @@ def main():
     # flight kernels of different frames share the chip and every per-kernel duration is inflated)
     iso_steps = min(args.steps, 5)
     workers[0].submit(("prof", "on")); workers[0].wait()
-    workers[0].submit(("steps", list(range(iso_steps)))); workers[0].wait()
+    workers[0].submit(("steps", iter(range(iso_steps)))); workers[0].wait()
     workers[0].submit(("prof", "off")); workers[0].wait()
     iso_report = dict(workers[0].report)
     if world > 1:
