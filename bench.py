@@ -184,11 +184,19 @@ def main():
             self.done = threading.Semaphore(0)
             self.jobs = []
             self.report = {}
+            self.error = None
             self.thread = threading.Thread(target=self.run, daemon=True)
             self.thread.start()
-            self.done.acquire()  # wait for setup
+            self.wait()  # wait for setup
 
         def run(self):
+            try:
+                self.run_inner()
+            except BaseException as e:      # a dead worker must fail the run, not leave the main thread waiting
+                self.error = e
+                self.done.release()
+
+        def run_inner(self):
             _lib.init(local_rank)
             self.pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(workload == "unet"))
             self.predictor = None
@@ -236,6 +244,8 @@ def main():
 
         def wait(self):
             self.done.acquire()
+            if self.error is not None:
+                raise RuntimeError("bench worker %d failed: %r" % (self.wid, self.error))
 
     workers = [Worker(w) for w in range(nthreads)]
     del st, st_flip

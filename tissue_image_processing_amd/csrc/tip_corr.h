@@ -155,14 +155,19 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
 }
 
 // ---- fast (NOT bit-exact) long pass for the certified argmax: float32 math, FMA allowed -----------------------------------
-// Same tiling as k_corr_long_f32; every lane slides R outputs with float32 left/right register windows:
-//     acc[i] = fma(L[i] + Rr[i], w[d], acc[i])        -> one v_add_f32 + one v_fma_f32 per output and tap
-// (measured on gfx950: scalar v_fma_f32 issues at twice the rate of v_pk_fma_f32, so packing buys nothing and the
-// odd/even pair shuffles it needs cost as much as the arithmetic).  The tap loop is unrolled R times so the window
-// rotation is pure register renaming; per tap a wave reads 2 window words + 1 broadcast tap from LDS for R outputs.
+// Same tiling as k_corr_long_f32; every lane slides R = 2H outputs.
+//   VAR 1 (default): outputs j and j+H share one register pair,
+//       acc[j] = pk_fma(L[j] + Rr[j], {w, w}, acc[j]),   L[j] = {x[j-d], x[j+H-d]},  Rr[j] = {x[j+d], x[j+H+d]}
+//     = one v_pk_add_f32 + one v_pk_fma_f32 per TWO outputs and tap.  Pairing outputs H apart (not neighbours) makes the
+//     window slide a pure renaming of whole pairs (L[j] <- L[j+1]); the one new pair per side and tap is read from LDS
+//     through a volatile pointer -- otherwise the compiler notices that half of it is already in a register and assembles
+//     the pair with v_mov, which costs as much as the arithmetic it saves.  Needs radius % H == 0.
+//   VAR 0: scalar v_add_f32 + v_fmac_f32 per output and tap (any radius).
 // Error vs the exact pass: every term is non-negative, so |fast - exact| <= ((1+u)^(r+3) - 1) * exact, u = 2^-24
 // (tap rounding + pair-sum rounding + at most r+1 FMA roundings); see k_argmax_certify for how the bound is used.
-template <int AXIS, int TO, int NW, int R>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int AXIS, int TO, int NW, int R, int VAR>
 __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X,
                                                         TapsF taps)
 {
@@ -194,26 +199,64 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
         const bool active = p0 + o0 < len;  // wave-uniform
         if (!STAGED && !active) break;
         const float *ctr = tile + (r + o0) * LS + lane;
-        float acc[R], L[R], Rr[R];
+        typedef __attribute__((address_space(3))) const volatile float *lds_cvf32;   // (a plain volatile pointer decays to flat loads)
+        constexpr int H = R / 2;
+        float res[R];
         if (active) {
             const float wc = wl[r];
+            if constexpr (VAR == 0) {   // scalar: one v_add_f32 + one v_fmac_f32 per output and tap
+                float acc[R], L[R], Rr[R];
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                acc[i] = ctr[i * LS] * wc;
-                L[i] = ctr[(i - r) * LS];
-                Rr[i] = ctr[(i + r) * LS];
-            }
+                for (int i = 0; i < R; ++i) {
+                    acc[i] = ctr[i * LS] * wc;
+                    L[i] = ctr[(i - r) * LS];
+                    Rr[i] = ctr[(i + r) * LS];
+                }
 #pragma unroll R
-            for (int d = r; d >= 1; --d) {
-                const float w = wl[r - d];
+                for (int d = r; d >= 1; --d) {
+                    const float w = wl[r - d];
 #pragma unroll
-                for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(L[i] + Rr[i], w, acc[i]);
+                    for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(L[i] + Rr[i], w, acc[i]);
 #pragma unroll
-                for (int i = 0; i < R - 1; ++i) L[i] = L[i + 1];
-                L[R - 1] = ctr[(R - d) * LS];
+                    for (int i = 0; i < R - 1; ++i) L[i] = L[i + 1];
+                    L[R - 1] = ctr[(R - d) * LS];
 #pragma unroll
-                for (int i = R - 1; i > 0; --i) Rr[i] = Rr[i - 1];
-                Rr[0] = ctr[(d - 1) * LS];
+                    for (int i = R - 1; i > 0; --i) Rr[i] = Rr[i - 1];
+                    Rr[0] = ctr[(d - 1) * LS];
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) res[i] = acc[i];
+            } else {
+                f32x2 acc[H], L[H], Rr[H];
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    acc[j] = f32x2{ctr[j * LS], ctr[(j + H) * LS]} * wc;
+                    L[j] = f32x2{ctr[(j - r) * LS], ctr[(j + H - r) * LS]};
+                    Rr[j] = f32x2{ctr[(j + r) * LS], ctr[(j + H + r) * LS]};
+                }
+                // H taps per trip, written as a constant-trip inner loop (the radius must be a multiple of H: checked by
+                // the launcher) so that it is fully unrolled and the window rotation is pure renaming
+                for (int db = r; db >= H; db -= H) {
+#pragma unroll
+                    for (int kk = 0; kk < H; ++kk) {
+                        const int d = db - kk;
+                        const float w = wl[r - d];
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc[j] = __builtin_elementwise_fma(L[j] + Rr[j], f32x2{w, w}, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < H - 1; ++j) L[j] = L[j + 1];
+#pragma unroll
+                        for (int j = H - 1; j > 0; --j) Rr[j] = Rr[j - 1];
+                        // volatile LDS reads: never merged with, or replaced by copies of, words already in registers
+                        // (same-run A/B on MI355X: this 0.80 ms per pass, "laundered" non-volatile pointers 0.865 ms,
+                        // the scalar variant 0.845 / 0.885 ms)
+                        lds_cvf32 q = (lds_cvf32)ctr;
+                        L[H - 1] = f32x2{q[(H - d) * LS], q[(2 * H - d) * LS]};
+                        Rr[0] = f32x2{q[(d - 1) * LS], q[(H + d - 1) * LS]};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < H; ++j) { res[j] = acc[j].x; res[j + H] = acc[j].y; }
             }
         }
         if (STAGED) {
@@ -221,7 +264,7 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
             __syncthreads();            // every wave has finished reading the input tile
             if (active) {
 #pragma unroll
-                for (int i = 0; i < R; ++i) tile[lane * OS + o0 + i] = acc[i];
+                for (int i = 0; i < R; ++i) tile[lane * OS + o0 + i] = res[i];
             }
             __syncthreads();
             for (int l = wave; l < 64; l += NW) {
@@ -234,8 +277,8 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int pp = p0 + o0 + i;
-                if (AXIS == 1) { if (pp < Y) dst[(long)pp * X + line] = acc[i]; }
-                else { if (pp < X) dst[(long)line * X + pp] = acc[i]; }
+                if (AXIS == 1) { if (pp < Y) dst[(long)pp * X + line] = res[i]; }
+                else { if (pp < X) dst[(long)line * X + pp] = res[i]; }
             }
         }
     }

@@ -347,18 +347,19 @@ __global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restri
 
 // (waves per block) * 100 + (outputs per lane and group) of the fast sigma-30 passes; see k_corr_long_fast
 #ifndef FAST_CFG_Y
-#define FAST_CFG_Y 1616
+#define FAST_CFG_Y 11616
 #endif
 #ifndef FAST_CFG_X
-#define FAST_CFG_X 1616
+#define FAST_CFG_X 11616
 #endif
 
-template <int AXIS, int NW, int R>
+template <int AXIS, int NW, int R, int VAR>
 static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
     const int r = t.n >> 1;
+    if (VAR != 0 && r % (R / 2)) return fail(TIP_ERR_ARG, "fast pass: radius %d is not a multiple of %d", r, R / 2);
     const size_t lds = (size_t)(256 + 2 * r) * (AXIS == 1 ? 64 : 65) * sizeof(float);
-    auto k = k_corr_long_fast<AXIS, 256, NW, R>;
+    auto k = k_corr_long_fast<AXIS, 256, NW, R, VAR>;
     TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid = AXIS == 1 ? dim3(cdiv(X, 64), cdiv(Y, 256), Zs) : dim3(cdiv(Y, 64), cdiv(X, 256), Zs);
     TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(NW * 64), lds, in, out, Zs, Y, X, t);
@@ -368,12 +369,10 @@ static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, co
 template <int AXIS>
 static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
-    switch (cfg) {
-    case 1608: return launch_fast_cfg<AXIS, 16, 8>(in, out, Zs, Y, X, t);
-    case 1616: return launch_fast_cfg<AXIS, 16, 16>(in, out, Zs, Y, X, t);
-    case 816: return launch_fast_cfg<AXIS, 8, 16>(in, out, Zs, Y, X, t);
-    case 832: return launch_fast_cfg<AXIS, 8, 32>(in, out, Zs, Y, X, t);
-    case 432: return launch_fast_cfg<AXIS, 4, 32>(in, out, Zs, Y, X, t);
+    if (cfg / 10000 == 1 && ((t.n >> 1) % 8)) cfg -= 10000;   // the packed variant needs radius % H == 0
+    switch (cfg) {   // variant * 10000 + waves * 100 + outputs per lane
+    case 1616: return launch_fast_cfg<AXIS, 16, 16, 0>(in, out, Zs, Y, X, t);
+    case 11616: return launch_fast_cfg<AXIS, 16, 16, 1>(in, out, Zs, Y, X, t);
     default: return fail(TIP_ERR_ARG, "unknown fast-pass configuration %d", cfg);
     }
 }
