@@ -406,6 +406,7 @@ __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict_
 }
 
 // one block per uncertified pixel: exact score of every candidate plane, then first-maximum argmax among them
+constexpr int FIX_UL = 16;
 __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restrict__ zvol, const float *__restrict__ score, int Z, int Y,
                                                           int X, Taps taps, const int *__restrict__ unc_list,
                                                           const int *__restrict__ unc_count, int *__restrict__ best_z)
@@ -431,9 +432,20 @@ __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restric
             if (threadIdx.x < 2 * r + 1) {
                 const int xx = clampi(x + (int)threadIdx.x - r, 0, X - 1);
                 double tmp = (double)vol[(long)y * X + xx] * taps.w[r];
-                for (int d = r; d >= 1; --d)
-                    tmp += ((double)vol[(long)clampi(y - d, 0, Y - 1) * X + xx] + (double)vol[(long)clampi(y + d, 0, Y - 1) * X + xx]) *
-                           taps.w[r - d];
+                // the sum is serial (scipy's order) but the loads are not: 2 * FIX_UL per trip in flight (the kernel is bound by
+                // global-load latency, not by arithmetic)
+                for (int d0 = r; d0 >= 1; d0 -= FIX_UL) {
+                    float a[FIX_UL], b[FIX_UL];
+#pragma unroll
+                    for (int u = 0; u < FIX_UL; ++u) {
+                        const int d = max(d0 - u, 1);
+                        a[u] = vol[(long)clampi(y - d, 0, Y - 1) * X + xx];
+                        b[u] = vol[(long)clampi(y + d, 0, Y - 1) * X + xx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < FIX_UL; ++u)
+                        if (d0 - u >= 1) tmp += ((double)a[u] + (double)b[u]) * taps.w[r - (d0 - u)];
+                }
                 c[threadIdx.x] = (float)tmp;   // exact y pass, rounded to float32 like scipy's intermediate
             }
             __syncthreads();
