@@ -53,6 +53,8 @@ struct WsInfo {           // device-resident scalars
     int n_markers;
     int changed, undecided;          // per-iteration counters (mode A) / frontier, pending (mode B)
     int unfinished, pad_;            // endgame: components whose replay hit the step limit
+    int changed_part[64];            // tile / component kernels spread their `changed` adds over 64 words: thousands of
+                                     // same-address atomics per launch serialise in L2 (host adds them up)
     unsigned long long fb_v, fb_k;   // fallback reduction
     unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
 };
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         tile_und[tile] = s_und;
         tile_front[tile] = s_front;
         changed_cur[tile] = s_chg > 0;
-        if (s_chg > 0) atomicAdd(&info->changed, s_chg);
+        if (s_chg > 0) atomicAdd(&info->changed_part[tile & 63], s_chg);
         if (dbg) {
             atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
             atomicAdd(&info->dbg_tiles, 1ULL);
@@ -706,7 +708,7 @@ __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v
     }
     for (int k = lane; k < m; k += 64)
         if (clab[k] != 0) st[cgi[k]] = pack_st(clab[k], ctr[k]);
-    if (lane == 0 && committed) atomicAdd(&info->changed, committed);
+    if (lane == 0 && committed) atomicAdd(&info->changed_part[blockIdx.x & 63], committed);
     if (lane == 0 && committed == max_steps) atomicAdd(&info->unfinished, 1);   // (may have been finished exactly: harmless)
 }
 
@@ -791,11 +793,13 @@ __global__ void k_ws_info_init(WsInfo *info)
 {
     info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
 }
 __global__ void k_ws_iter_reset(WsInfo *info)
 {
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
 }
 
@@ -830,6 +834,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     WsInfo h;
     TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
     TIP_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
     c.last_ws_labels = h.n_markers;
     int flags = h.ties ? 1 : 0;
     const bool two_valued = h.n_other == 0 && h.emin != h.emax;
@@ -843,6 +848,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_LAUNCH("bfs_tent", k_bfs_tent, dim3(cdiv(X, 256), Y), dim3(256), 0, st, tent, fate, Y, X, gen, info);
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
             if (h.changed == 0) break;
             int pending = h.undecided;
             while (pending > 0) {
@@ -850,6 +856,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_LAUNCH("bfs_resolve", k_bfs_resolve, dim3(cdiv(X, 256), Y), dim3(256), 0, (const int *)tent, fate, Y, X, info);
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
                 if (h.changed == 0 && h.undecided > 0) return fail(TIP_ERR_HIP, "watershed: BFS resolve made no progress");
                 pending = h.undecided;
             }
@@ -893,6 +900,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             }
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
             if (getenv("TIP_WS_DEBUG"))
                 fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d\n", iter, wide ? "wide" : "fast",
                         h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed);
@@ -945,6 +953,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                                (const int *)flag, (const int *)off, (const int *)cellsbuf, (const int *)slot, WS_END_STEPS, info);
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
                 if (getenv("TIP_WS_DEBUG"))
                     fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d, unfinished %d\n", ncomp, h.changed, h.undecided, h.unfinished);
                 endgames++;
@@ -969,6 +978,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_LAUNCH("ws_fb_commit", k_ws_fb_commit, dim3(1), dim3(1), 0, img, st, Y, X, info);
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
             if (h.fb_k == ~0ULL) break;  // the remaining pixels are enclosed by lines: they stay 0, as in the serial flood
             fallbacks++;
             // wake the tile of the committed pixel (its 3x3 neighbourhood follows through the activity rule)
