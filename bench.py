@@ -135,12 +135,12 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight per GPU: host threads, each with its own HIP stream and workspaces (the library "
                          "is re-entrant per thread, like the reference's Qt workers); frames are independent units")
     args = ap.parse_args()
