@@ -18,7 +18,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VALU_PEAK_TF = 78.6   # MI355X datasheet FP64 vector (spec); FP32 vector is 157.3 TF in the guide
+FP64_VALU_PEAK_TF = 78.6   # MI355X datasheet FP64 vector (spec)
+FP32_VALU_PEAK_TF = 157.3  # MI355X_MICROARCH.md: FP32 vector (packed FMA)
 
 
 def algorithmic_bytes(kernel, C, Z, Y, X):
@@ -335,6 +336,15 @@ def main():
         timed = merge(timed_reports)
         roof_timed = roofline_of(timed)
         kernels = kernel_table(iso_report, iso_steps)
+        # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are FP32-VALU bound, not HBM bound: 120 tap pairs x
+        # (add + fma) + 1 multiply per output = 361 flop per voxel and pass; peak = MI355X FP32 vector (packed FMA) rate
+        valu = {}
+        for kname in ("score_fast_y", "score_fast_x"):
+            if kname in iso_report and iso_report[kname][0]:
+                cnt_k, ms_k = iso_report[kname]
+                tf = Z * Y * X * 361.0 / (ms_k / cnt_k / 1e3) / 1e12
+                valu[kname] = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
         out = {
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -346,7 +356,7 @@ def main():
                 "unet": "surface_projection+unet_segmentation(%s,random-init)+cell_tables" % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}[workload]),
                 "frames_per_step": world, "frames_in_flight_per_gpu": nthreads,
                 "parallelism": "frame-sharded dp%d, no data-path collective" % world},
-            "roofline": roof, "roofline_timed_region": roof_timed, "kernels": kernels,
+            "roofline": roof, "roofline_timed_region": roof_timed, "roofline_valu": valu, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             Ys, Xs = min(Y, 1408), min(X, 1408)
