@@ -325,6 +325,85 @@ class TissueHipMixin(object):
             yield frame
         return 0
 
+    # ---- T1 -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def tracking_dist_func(first, second):
+        """ti.py:1935-1938: the linking distance between two (cy, cx, area) features."""
+        return np.sqrt((first[0] - second[0]) ** 2 + (first[1] - second[1]) ** 2 +
+                       0.5 * (np.sqrt(first[2]) - np.sqrt(second[2])) ** 2)
+
+    def track_cells_iterator_with_trackpy(self, initial_frame=1, final_frame=-1, images=None, image_in_memory=False):
+        """ti.py:1881-1933.  Upstream hands the per-frame (cy, cx, area) tables -- valid, non-empty cells, centroids moved
+        by the cumulative drift -- to trackpy.link_df_iter(search_range=100, adaptive_stop=10, memory=3) and writes
+        `label = particle + 1`.  trackpy is a third-party package that is not part of the reference: the linking model
+        is restated in linking.py for these parameters (PARITY UNPINNED, see there).  Generator yielding frame numbers."""
+        from .linking import FrameLinker, embed
+        last = self.number_of_frames if final_frame == -1 else final_frame
+        reuse_drifts = bool((self.drifts > 0).any())
+        linker = FrameLinker(search_range=100, adaptive_stop=10, memory=3)
+        refresh_next = False
+        total_dy = total_dx = 0.0
+        previous_frame = 0
+        for frame in range(initial_frame, last + 1):
+            if np.isnan(self.drifts[frame - 1, :]).any():
+                refresh_next = True
+            if self.valid_frames[frame - 1] == 0:
+                if not np.isnan(self.drifts[frame - 1, 0]):
+                    self.drifts[frame - 1, :] = np.nan
+                    refresh_next = True
+                continue
+            table = self.get_cells_info(frame)
+            if table is None:
+                continue
+            rows = table.index[(table.valid.to_numpy() == 1) & (table.empty_cell.to_numpy() == 0)]
+            if frame > initial_frame:
+                if reuse_drifts and not refresh_next:
+                    dy, dx = self.drifts[frame - 1, 0], self.drifts[frame - 1, 1]
+                else:
+                    dy, dx = self.update_drift(frame, previous_frame, images=images, image_in_memory=image_in_memory)
+                total_dy += dy
+                total_dx += dx
+            previous_frame = frame
+            if len(rows) == 0:      # (upstream would fail on an empty table; nothing to link in this frame)
+                continue
+            particles = linker.link(embed(table.loc[rows, "cy"].to_numpy() + total_dy, table.loc[rows, "cx"].to_numpy() + total_dx,
+                                          table.loc[rows, "area"].to_numpy()))
+            table.loc[rows, "label"] = particles + 1
+            self.cells_number = max(self.cells_number, int(particles.max()) + 1)
+            self.fix_duplicated_label_cells_in_frame(frame)
+            yield frame
+        return 0
+
+    def track_cells_with_trackpy(self, initial_frame=1, final_frame=-1, images=None, image_in_memory=False):
+        """ti.py:1874-1879: run the generator to its end, return the last frame it finished."""
+        last_frame = initial_frame
+        for frame in self.track_cells_iterator_with_trackpy(initial_frame, final_frame, images, image_in_memory):
+            last_frame = frame
+        return last_frame
+
+    def fix_duplicated_label_cells_in_frame(self, frame):
+        """ti.py:4288-4310: of the cells sharing a track id the first valid one (else the first) keeps it; the others get
+        `row index + 1`, or ids above the frame's maximum where that is taken too."""
+        table = self.get_cells_info(frame)
+        if table is None:
+            return 0
+        ids = table.label.to_numpy()
+        present = np.unique(ids)
+        losers = []
+        for dup in np.unique(ids[table.label.duplicated().to_numpy()]):
+            group = table.index[ids == dup]
+            ok = group[table.loc[group, "valid"].to_numpy() == 1]
+            winner = ok[0] if len(ok) else group[0]
+            losers.extend(i for i in group if i != winner)
+        if not losers:
+            return 0
+        losers = np.asarray(losers)
+        fresh = losers + 1
+        clash = np.isin(fresh, present)
+        fresh[clash] = present.max() + np.arange(1, int(clash.sum()) + 1)
+        table.loc[losers, "label"] = fresh
+        return 0
+
     @staticmethod
     def calculate_refine_drift(previous_image, current_image, course_shift_x, course_shift_y):
         """ti.py:1941-1980: crop the overlap given by the floored coarse shift, refine by phase cross-correlation."""
