@@ -142,7 +142,7 @@ TIP_API int tip_lut_gather_i32(const int32_t *labels, const int64_t *lut, int64_
 
 /* ---- drift: skimage.registration.phase_cross_correlation(ref, mov, upsample_factor) ---------------------------- */
 /* (ti.py:1976-1977, 2029-2030 update_drift / calculate_refine_drift; bim.py:522-536 calculate_drift).               */
-/* dtype: 0 float32, 1 float64, 3 uint16; extents powers of two <= 4096.  out4 = whole-pixel peak (row, col) of       */
+/* dtype: 0 float32, 1 float64, 3 uint16; extents in [2, 4096] (powers of two: radix-2 FFT rows; anything else: Bluestein).  out4 = whole-pixel peak (row, col) of       */
 /* |ifft2(F1 conj F2)| and the peak (row, col) on the ceil(1.5*upsample)^2 upsampled grid; the caller forms the shift  */
 /* exactly as skimage does (wrap past the midpoint, round to the grid, add (fine - floor(region/2)) / upsample).       */
 TIP_API int tip_phase_correlation(const void *ref, const void *mov, int dtype, int y, int x, int upsample, int64_t *out4);

@@ -33,8 +33,8 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, sp
     b = np.ascontiguousarray(b)
     ny, nx = a.shape
     for n in (ny, nx):
-        if n < 2 or n > 4096 or (n & (n - 1)):
-            raise NotImplementedError("MI355X phase correlation takes power-of-two extents up to 4096 (got %dx%d)" % (ny, nx))
+        if n < 2 or n > 4096:
+            raise NotImplementedError("MI355X phase correlation takes extents in [2, 4096] (got %dx%d)" % (ny, nx))
     out = (ctypes.c_int64 * 4)()
     _lib.check(_lib.lib().tip_phase_correlation(_lib.ptr(a), _lib.ptr(b), dt, ny, nx, int(upsample_factor), out))
     shape = np.array([ny, nx])

@@ -59,6 +59,98 @@ __global__ void __launch_bounds__(256) k_fft_rows(cplx *__restrict__ data, const
     for (int i = threadIdx.x; i < N; i += blockDim.x) p[i] = row[i];
 }
 
+// ---- arbitrary lengths: Bluestein's chirp-z on top of the power-of-two butterflies --------------------------------------
+// X[k] = b[k] * sum_n (x[n] b[n]) conj(b[k-n]),  b[n] = exp(-i pi n^2 / N): a length-N DFT as a circular convolution of
+// length M = 2^ceil(log2(2N-1)), done in LDS per row: forward DIF (natural in, bit-reversed out), pointwise product with
+// the chirp's transform (stored in the same bit-reversed order), inverse DIT (bit-reversed in, natural out).
+__global__ void __launch_bounds__(256) k_chirp(cplx *__restrict__ b, int N)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const long r = ((long)n * n) % (2L * N);          // n^2 mod 2N exactly: the phase only matters modulo 2 pi
+    double sn, cs;
+    sincospi(-(double)r / (double)N, &sn, &cs);
+    b[n] = make_double2(cs, sn);
+}
+
+__device__ __forceinline__ void lds_dif(cplx *row, const cplx *__restrict__ tw, int M, int logM)
+{
+    for (int s = logM; s >= 1; --s) {
+        const int half = 1 << (s - 1), step = M >> s;
+        for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
+            const int grp = t / half, pos = t - grp * half;
+            const int i0 = grp * (half << 1) + pos, i1 = i0 + half;
+            const cplx a = row[i0], c = row[i1];
+            row[i0] = make_double2(a.x + c.x, a.y + c.y);
+            row[i1] = cmul(make_double2(a.x - c.x, a.y - c.y), tw[pos * step]);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void lds_dit_inverse(cplx *row, const cplx *__restrict__ tw, int M, int logM)
+{
+    for (int s = 1; s <= logM; ++s) {
+        const int half = 1 << (s - 1), step = M >> s;
+        for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
+            const int grp = t / half, pos = t - grp * half;
+            const int i0 = grp * (half << 1) + pos, i1 = i0 + half;
+            cplx w = tw[pos * step];
+            w.y = -w.y;
+            const cplx a = row[i0], c = cmul(row[i1], w);
+            row[i0] = make_double2(a.x + c.x, a.y + c.y);
+            row[i1] = make_double2(a.x - c.x, a.y - c.y);
+        }
+        __syncthreads();
+    }
+}
+
+// transform of the wrapped conjugate chirp, left in DIF (bit-reversed) order
+__global__ void __launch_bounds__(256) k_bluestein_filter(cplx *__restrict__ cf, const cplx *__restrict__ b, const cplx *__restrict__ tw,
+                                                          int N, int M, int logM)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 row[];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        cplx v = make_double2(0.0, 0.0);
+        if (m < N) v = make_double2(b[m].x, -b[m].y);
+        else if (m > M - N) v = make_double2(b[M - m].x, -b[M - m].y);
+        row[m] = v;
+    }
+    __syncthreads();
+    lds_dif(row, tw, M, logM);
+    for (int m = threadIdx.x; m < M; m += blockDim.x) cf[m] = row[m];
+}
+
+// in-place DFT of every row of length N (any N with 2N-1 <= M); inverse = conjugate in, conjugate out (no scaling)
+__global__ void __launch_bounds__(256) k_fft_rows_bluestein(cplx *__restrict__ data, const cplx *__restrict__ tw,
+                                                            const cplx *__restrict__ b, const cplx *__restrict__ cf, int N, int M,
+                                                            int logM, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 row[];
+    cplx *p = data + (long)blockIdx.x * N;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        cplx v = make_double2(0.0, 0.0);
+        if (i < N) {
+            v = p[i];
+            if (inverse) v.y = -v.y;
+            v = cmul(v, b[i]);
+        }
+        row[i] = v;
+    }
+    __syncthreads();
+    lds_dif(row, tw, M, logM);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) row[i] = cmul(row[i], cf[i]);
+    __syncthreads();
+    lds_dit_inverse(row, tw, M, logM);
+    const double sc = 1.0 / (double)M;
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        cplx v = cmul(row[k], b[k]);
+        v.x *= sc; v.y *= sc;
+        if (inverse) v.y = -v.y;
+        p[k] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_transpose_c(const cplx *__restrict__ in, cplx *__restrict__ out, int rows, int cols)
 {
     __shared__ double2 t[16][17];
@@ -152,13 +244,56 @@ __global__ void __launch_bounds__(64) k_updft2(const cplx *__restrict__ Ky, cons
 
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
-static int fft2_inplace(cplx *a, cplx *tmp, int Ny, int Nx, const cplx *twx, const cplx *twy, int inverse, bool leave_transposed)
+// per-length tables: power of two -> twiddles only; any other length -> Bluestein (chirp, filter transform, twiddles of M)
+struct RowPlan {
+    int N = 0, M = 0, logM = 0;
+    bool pow2 = true;
+    cplx *tw = nullptr, *chirp = nullptr, *cf = nullptr;
+};
+
+static int make_plan(RowPlan &pl, int N, WsGuard &ws)
 {
-    TIP_HIP(hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    // rows (length Nx), transpose, rows (length Ny) -> result transposed (Nx rows of Ny) in tmp; optionally transpose back into a
-    TIP_LAUNCH("fft_rows", k_fft_rows, dim3(Ny), dim3(256), (size_t)Nx * sizeof(cplx), a, twx, Nx, ilog2(Nx), inverse);
+    pl.N = N;
+    pl.pow2 = (N & (N - 1)) == 0;
+    pl.M = N;
+    if (!pl.pow2) { pl.M = 1; while (pl.M < 2 * N - 1) pl.M <<= 1; }
+    pl.logM = ilog2(pl.M);
+    pl.tw = ws.get<cplx>(pl.M / 2 + 1);
+    if (!pl.tw) return TIP_ERR_NOMEM;
+    TIP_LAUNCH("twiddles", k_twiddles, dim3(cdiv(pl.M / 2, 256)), dim3(256), 0, pl.tw, pl.M);
+    if (!pl.pow2) {
+        pl.chirp = ws.get<cplx>(N);
+        pl.cf = ws.get<cplx>(pl.M);
+        if (!pl.chirp || !pl.cf) return TIP_ERR_NOMEM;
+        TIP_LAUNCH("chirp", k_chirp, dim3(cdiv(N, 256)), dim3(256), 0, pl.chirp, N);
+        TIP_HIP(hipFuncSetAttribute((const void *)k_bluestein_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        TIP_LAUNCH("bluestein_filter", k_bluestein_filter, dim3(1), dim3(256), (size_t)pl.M * sizeof(cplx), pl.cf, (const cplx *)pl.chirp,
+                   (const cplx *)pl.tw, N, pl.M, pl.logM);
+    }
+    return TIP_OK;
+}
+
+static int fft_rows(cplx *data, int nrows, const RowPlan &pl, int inverse)
+{
+    if (pl.pow2) {
+        TIP_HIP(hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        TIP_LAUNCH("fft_rows", k_fft_rows, dim3(nrows), dim3(256), (size_t)pl.N * sizeof(cplx), data, (const cplx *)pl.tw, pl.N, pl.logM,
+                   inverse);
+    } else {
+        TIP_HIP(hipFuncSetAttribute((const void *)k_fft_rows_bluestein, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        TIP_LAUNCH("fft_rows_bluestein", k_fft_rows_bluestein, dim3(nrows), dim3(256), (size_t)pl.M * sizeof(cplx), data,
+                   (const cplx *)pl.tw, (const cplx *)pl.chirp, (const cplx *)pl.cf, pl.N, pl.M, pl.logM, inverse);
+    }
+    return TIP_OK;
+}
+
+// rows (length Nx), transpose, rows (length Ny) -> result transposed (Nx rows of Ny) in tmp; optionally transposed back into a
+static int fft2_inplace(cplx *a, cplx *tmp, int Ny, int Nx, const RowPlan &px, const RowPlan &py, int inverse, bool leave_transposed)
+{
+    int rc;
+    if ((rc = fft_rows(a, Ny, px, inverse))) return rc;
     TIP_LAUNCH("transpose_c", k_transpose_c, dim3(cdiv(Nx, 16), cdiv(Ny, 16)), dim3(256), 0, (const cplx *)a, tmp, Ny, Nx);
-    TIP_LAUNCH("fft_rows", k_fft_rows, dim3(Nx), dim3(256), (size_t)Ny * sizeof(cplx), tmp, twy, Ny, ilog2(Ny), inverse);
+    if ((rc = fft_rows(tmp, Nx, py, inverse))) return rc;
     if (!leave_transposed)
         TIP_LAUNCH("transpose_c", k_transpose_c, dim3(cdiv(Ny, 16), cdiv(Nx, 16)), dim3(256), 0, (const cplx *)tmp, a, Nx, Ny);
     return TIP_OK;
@@ -177,17 +312,18 @@ int phase_correlation_dev(const void *ref, const void *mov, int dtype, int Ny, i
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
     if (!ref || !mov || !out4_host) return fail(TIP_ERR_ARG, "phase_correlation: null pointer");
-    if (Ny < 2 || Nx < 2 || Ny > 4096 || Nx > 4096 || (Ny & (Ny - 1)) || (Nx & (Nx - 1)))
-        return fail(TIP_ERR_UNSUPPORTED, "phase_correlation: extents must be powers of two in [2, 4096] (got %dx%d)", Ny, Nx);
+    if (Ny < 2 || Nx < 2 || Ny > 4096 || Nx > 4096)
+        return fail(TIP_ERR_UNSUPPORTED, "phase_correlation: extents must lie in [2, 4096] (got %dx%d)", Ny, Nx);
     if (upsample < 1 || upsample > 1000) return fail(TIP_ERR_ARG, "phase_correlation: upsample_factor %d", upsample);
     const long n = (long)Ny * Nx;
     const int region = upsample > 1 ? (int)ceil(upsample * 1.5) : 0;
     WsGuard ws;
     cplx *A = ws.get<cplx>(n), *B = ws.get<cplx>(n), *T1 = ws.get<cplx>(n), *T2 = ws.get<cplx>(n);
-    cplx *twx = ws.get<cplx>(Nx / 2 + 1), *twy = ws.get<cplx>(Ny / 2 + 1);
     unsigned long long *best = ws.get<unsigned long long>(4);
-    if (!A || !B || !T1 || !T2 || !twx || !twy || !best) return TIP_ERR_NOMEM;
+    if (!A || !B || !T1 || !T2 || !best) return TIP_ERR_NOMEM;
     int rc;
+    RowPlan plx, ply;
+    if ((rc = make_plan(plx, Nx, ws)) || (rc = make_plan(ply, Ny, ws))) return rc;
     for (int w = 0; w < 2; ++w) {
         const void *src = w == 0 ? ref : mov;
         cplx *dst = w == 0 ? A : B;
@@ -197,17 +333,15 @@ int phase_correlation_dev(const void *ref, const void *mov, int dtype, int Ny, i
         else return fail(TIP_ERR_ARG, "phase_correlation: dtype %d (0 f32, 1 f64, 3 u16)", dtype);
         if (rc) return rc;
     }
-    TIP_LAUNCH("twiddles", k_twiddles, dim3(cdiv(Nx / 2, 256)), dim3(256), 0, twx, Nx);
-    TIP_LAUNCH("twiddles", k_twiddles, dim3(cdiv(Ny / 2, 256)), dim3(256), 0, twy, Ny);
-    if ((rc = fft2_inplace(A, T1, Ny, Nx, twx, twy, 0, true))) return rc;   // T1 = F1^T
-    if ((rc = fft2_inplace(B, T2, Ny, Nx, twx, twy, 0, true))) return rc;   // T2 = F2^T
+    if ((rc = fft2_inplace(A, T1, Ny, Nx, plx, ply, 0, true))) return rc;   // T1 = F1^T
+    if ((rc = fft2_inplace(B, T2, Ny, Nx, plx, ply, 0, true))) return rc;   // T2 = F2^T
     cplx *PT = A;                                                            // P^T = F1^T * conj(F2^T)
     TIP_LAUNCH("cmul_conj", k_cmul_conj, dim3(cdiv(n, 256)), dim3(256), 0, (const cplx *)T1, (const cplx *)T2, PT, n);
     // cross-correlation = ifft2(P): inverse transform of P^T (Nx rows of Ny) -> rows Ny-point, transpose, rows Nx-point
     TIP_HIP(hipMemcpyAsync(B, PT, n * sizeof(cplx), hipMemcpyDeviceToDevice, c.stream));
-    TIP_LAUNCH("fft_rows", k_fft_rows, dim3(Nx), dim3(256), (size_t)Ny * sizeof(cplx), B, (const cplx *)twy, Ny, ilog2(Ny), 1);
+    if ((rc = fft_rows(B, Nx, ply, 1))) return rc;
     TIP_LAUNCH("transpose_c", k_transpose_c, dim3(cdiv(Ny, 16), cdiv(Nx, 16)), dim3(256), 0, (const cplx *)B, T1, Nx, Ny);
-    TIP_LAUNCH("fft_rows", k_fft_rows, dim3(Ny), dim3(256), (size_t)Nx * sizeof(cplx), T1, (const cplx *)twx, Nx, ilog2(Nx), 1);
+    if ((rc = fft_rows(T1, Ny, plx, 1))) return rc;
     TIP_HIP(hipMemsetAsync(best, 0, 8, c.stream));
     TIP_HIP(hipMemsetAsync(best + 1, 0xff, 8, c.stream));
     TIP_LAUNCH("absargmax", k_absargmax, dim3(cdiv(n, 256)), dim3(256), 0, (const cplx *)T1, n, best, best + 1);
