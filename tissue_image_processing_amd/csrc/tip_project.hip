@@ -390,19 +390,36 @@ static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int 
 __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict__ score, int Z, long P, int *__restrict__ best_z,
                                                         int *__restrict__ unc_list, int *__restrict__ unc_count)
 {
+    __shared__ int s_cnt[4], s_base;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    float b1 = score[p], b2 = -1.f;
-    int z1 = 0;
-    for (int z = 1; z < Z; ++z) {
-        const float s = score[(long)z * P + p];
-        if (s > b1) { b2 = b1; b1 = s; z1 = z; }
-        else if (s > b2) b2 = s;
+    bool certain = true;
+    if (p < P) {
+        float b1 = score[p], b2 = -1.f;
+        int z1 = 0;
+        for (int z = 1; z < Z; ++z) {
+            const float s = score[(long)z * P + p];
+            if (s > b1) { b2 = b1; b1 = s; z1 = z; }
+            else if (s > b2) b2 = s;
+        }
+        best_z[p] = z1;
+        // b1 == 0: every plane is exactly zero in the fast pass, hence (no underflow for uint16-derived data) in the exact one
+        certain = (b1 == 0.f) || (Z == 1) || (b1 * (1.f - CERT_EPS) > b2 * (1.f + CERT_EPS) + 1e-30f);
     }
-    best_z[p] = z1;
-    // b1 == 0: every plane is exactly zero in the fast pass, hence (no underflow for uint16-derived data) in the exact one
-    const bool certain = (b1 == 0.f) || (Z == 1) || (b1 * (1.f - CERT_EPS) > b2 * (1.f + CERT_EPS) + 1e-30f);
-    if (!certain) unc_list[atomicAdd(unc_count, 1)] = (int)p;
+    // append with one atomic per block (not per pixel: same-address atomics serialise in L2)
+    const unsigned long long m = __ballot(!certain);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(unc_count, tot) : 0;
+    }
+    __syncthreads();
+    if (!certain) {
+        int off = s_base + __popcll(m & ((1ULL << lane) - 1ULL));
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        unc_list[off] = (int)p;
+    }
 }
 
 // one block per uncertified pixel: exact score of every candidate plane, then first-maximum argmax among them
@@ -571,7 +588,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         }
         TIP_HIP(hipMemsetAsync(uncn, 0, sizeof(int), c.stream));
         TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(P, 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
-        TIP_LAUNCH("argmax_exact_fix", k_argmax_exact_fix, dim3(2048), dim3(256), 0, (const float *)B, (const float *)D, Zs, Y, X,
+        TIP_LAUNCH("argmax_exact_fix", k_argmax_exact_fix, dim3(8192), dim3(256), 0, (const float *)B, (const float *)D, Zs, Y, X,
                    k30, (const int *)unc, (const int *)uncn, bestz);
         TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
                    zsel_a, zmap, err);
