@@ -185,17 +185,20 @@ constexpr unsigned long long ST_LISTED = 1ULL << 32;
 struct T2 { double v; int i; };
 __device__ __forceinline__ bool t_lt(const T2 &a, const T2 &b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
 
+// one window cell: value slot and packed state side by side, so the flood rule fetches a neighbour with ONE 16-byte LDS read
+struct __attribute__((aligned(16))) WCell { double v; unsigned long long st; };
+
 struct TileView {
-    const double *sv;                  // LDS: undecided cell: its image value (= key value); labelled cell: its pop-time VALUE
-                                       // (its own value, or the puller's pop-time value for a pulled pixel)
-    const unsigned long long *sst;     // LDS: packed state (label | pop-time reference pixel << 32)
+    const WCell *cell;                 // LDS window.  .st: packed state (label | pop-time reference pixel << 32);
+                                       // .v: undecided cell: its image value (= key value); labelled cell: its pop-time
+                                       // VALUE (its own value, or the puller's pop-time value for a pulled pixel)
     unsigned short *vis;               // LDS: this thread's pocket list
     int budget;                        // pocket flood budget (cells)
     int WL;                            // window edge (tile + 2 * halo)
     int g00, X;                        // global linear index of window cell 0 (may be negative), image row length
     // global linear index of window cell c (meaningless for cells outside the image: those are LINE and never compared)
     __device__ __forceinline__ int gi(int c) const { const int cy = c / WL; return g00 + cy * X + (c - cy * WL); }
-    __device__ __forceinline__ T2 key(int c) const { return T2{sv[c], gi(c)}; }
+    __device__ __forceinline__ T2 key(int c) const { return T2{cell[c].v, gi(c)}; }
 };
 
 // Is undecided cell q (key < t) certain not to be labelled before time t?  Flood the pocket of undecided cells with
@@ -204,11 +207,10 @@ struct TileView {
 // Out of line to keep the everyday rule small -- so everything it needs travels BY VALUE in registers, with the LDS
 // arrays as address-space-3 pointers: a TileView reference would live on the (global-memory) stack and every field
 // access in the flood would be a scratch load (measured: a certificate round cost 400k cycles that way).
-typedef __attribute__((address_space(3))) const double *lds_cf64;
-typedef __attribute__((address_space(3))) const unsigned long long *lds_cu64;
+typedef __attribute__((address_space(3))) const WCell *lds_ccell;
 typedef __attribute__((address_space(3))) unsigned short *lds_u16;
 
-__device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, int budget, int WL, int g00, int X, int q, int asker,
+__device__ __forceinline__ bool ws_cert(lds_ccell cell, lds_u16 vis, int budget, int WL, int g00, int X, int q, int asker,
                                      double tvv, int tii)
 {
     const T2 t{tvv, tii};
@@ -224,12 +226,13 @@ __device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, 
             const int m = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
             if (m == asker) continue;
             const int gm = k == 0 ? gc - X : (k == 1 ? gc - 1 : (k == 2 ? gc + 1 : gc + X));
-            const unsigned long long sm = sst[m];
+            const double cmv = cell[m].v;
+            const unsigned long long sm = cell[m].st;
             const int l = st_lab(sm);
             if (l == LINE_LAB) continue;
             if (l > 0) {
-                if (t_lt(T2{sv[m], st_tref(sm)}, t)) return false;
-            } else if (t_lt(T2{sv[m], gm}, t)) {
+                if (t_lt(T2{cmv, st_tref(sm)}, t)) return false;
+            } else if (t_lt(T2{cmv, gm}, t)) {
                 bool seen = false;
                 for (int j = 0; j < nv; ++j) seen |= vis[j] == (unsigned short)m;
                 if (!seen) {
@@ -244,7 +247,7 @@ __device__ __forceinline__ bool ws_cert(lds_cf64 sv, lds_cu64 sst, lds_u16 vis, 
 
 __device__ __forceinline__ bool ws_cert(const TileView &tv, int q, int asker, double tvv, int tii)
 {
-    return ws_cert((lds_cf64)tv.sv, (lds_cu64)tv.sst, (lds_u16)tv.vis, tv.budget, tv.WL, tv.g00, tv.X, q, asker, tvv, tii);
+    return ws_cert((lds_ccell)tv.cell, (lds_u16)tv.vis, tv.budget, tv.WL, tv.g00, tv.X, q, asker, tvv, tii);
 }
 
 struct Decision { int lab; int ti; double tv; };  // lab == 0: no decision; (tv, ti) = pop time: value and reference pixel
@@ -257,10 +260,11 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
     Decision d{0, 0, 0.0};
     const int WL = tv.WL;
     const int q0 = c - WL, q1 = c - 1, q2 = c + 1, q3 = c + WL;
-    const unsigned long long s0 = tv.sst[q0], s1 = tv.sst[q1], s2 = tv.sst[q2], s3 = tv.sst[q3];
+    const WCell n0 = tv.cell[q0], n1 = tv.cell[q1], n2 = tv.cell[q2], n3 = tv.cell[q3];
+    const unsigned long long s0 = n0.st, s1 = n1.st, s2 = n2.st, s3 = n3.st;
     const int l0 = st_lab(s0), l1 = st_lab(s1), l2 = st_lab(s2), l3 = st_lab(s3);
     if (!(l0 > 0 || l1 > 0 || l2 > 0 || l3 > 0)) return d;
-    const double v0 = tv.sv[q0], v1 = tv.sv[q1], v2 = tv.sv[q2], v3 = tv.sv[q3], vc = tv.sv[c];
+    const double v0 = n0.v, v1 = n1.v, v2 = n2.v, v3 = n3.v, vc = tv.cell[c].v;
     const int g0 = gc - tv.X, g1 = gc - 1, g2 = gc + 1, g3 = gc + tv.X;
     int s_lab = 0, pull_lab = 0, pull_ti = 0;
     bool conflict = false, has_pull = false;
@@ -328,8 +332,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                                                   int *__restrict__ tile_front, int first, int max_rounds, int dbg, WsInfo *info)
 {
     constexpr int WL = WT + 2 * WH;
-    __shared__ double sv[WL * WL];
-    __shared__ unsigned long long sst[WL * WL];     // label | pop-time reference pixel << 32, one 8-byte word
+    __shared__ WCell cells[WL * WL];
     __shared__ unsigned short svis[WS_THREADS * WK];
     __shared__ unsigned short slist[2][WT * WT];
     __shared__ int s_n[2], s_any, s_und, s_chg, s_front;
@@ -370,23 +373,23 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
 #pragma unroll
         for (int u = 0; u < NLOAD; ++u) {
             const int c = threadIdx.x + u * WS_THREADS;
-            if (c < WL * WL) { sv[c] = lv[u]; sst[c] = ls[u]; }
+            if (c < WL * WL) { cells[c].v = lv[u]; cells[c].st = ls[u]; }
         }
     }
     if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_any = 0; s_und = 0; s_chg = 0; s_front = 0; }
     __syncthreads();
     const int g00 = gy0 * X + gx0;
-    TileView tv{sv, sst, svis + threadIdx.x * WK, WK, WL, g00, X};
+    TileView tv{cells, svis + threadIdx.x * WK, WK, WL, g00, X};
     // initial frontier: undecided interior cells next to a labelled cell
     unsigned was_und = 0;   // bit k: own interior cell k was undecided when the window was loaded
 #pragma unroll
     for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
-        if (st_lab(sst[c]) == 0) {
+        if (st_lab(cells[c].st) == 0) {
             was_und |= 1u << k;
-            if (st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 || st_lab(sst[c + WL]) > 0) {
-                sst[c] = ST_LISTED;
+            if (st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0) {
+                cells[c].st = ST_LISTED;
                 slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
             }
         }
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             dec[j].lab = 0; dec[j].ti = 0; dec[j].tv = 0.0;
             if (i < n) {
                 const int c = slist[cur][i];
-                if (st_lab(sst[c]) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
+                if (st_lab(cells[c].st) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
                 // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
             }
         }
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
                 continue;
             }
-            sst[c] = pack_st(dec[j].lab, dec[j].ti); sv[c] = dec[j].tv;
+            cells[c].st = pack_st(dec[j].lab, dec[j].ti); cells[c].v = dec[j].tv;
             s_any = 1;
             atomicAdd(&s_chg, 1);
             if (dec[j].lab > 0) {
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 for (int k = 0; k < 4; ++k) {
                     const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
                     const int qy = q / WL, qx = q - qy * WL;
-                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && atomicCAS(&sst[q], 0ULL, ST_LISTED) == 0ULL)
+                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
                         slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
                 }
             }
@@ -454,10 +457,10 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         if (!((was_und >> k) & 1u)) continue;   // decided before this launch (cells outside the image are LINE)
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
-        const unsigned long long sc = sst[c];
+        const unsigned long long sc = cells[c].st;
         if (st_lab(sc) == 0) {
             und++;
-            front += st_lab(sst[c - WL]) > 0 || st_lab(sst[c - 1]) > 0 || st_lab(sst[c + 1]) > 0 || st_lab(sst[c + WL]) > 0;
+            front += st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0;
         } else {
             st[(ty * WT + p / WT) * X + tx * WT + p % WT] = sc;   // only this tile writes its interior
         }
