@@ -19,7 +19,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6   # MI355X datasheet FP64 vector (spec)
-FP32_VALU_PEAK_TF = 157.3  # MI355X_MICROARCH.md: FP32 vector (packed FMA)
+FP32_VALU_PEAK_TF = 157.3  # MI355X_MICROARCH.md: FP32 vector (pure FMA stream; the passes' add+fma mix sustains 104-109)
 
 
 def algorithmic_bytes(kernel, C, Z, Y, X):

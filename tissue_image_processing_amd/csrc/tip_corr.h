@@ -162,7 +162,9 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
 //     window slide a pure renaming of whole pairs (L[j] <- L[j+1]); the one new pair per side and tap is read from LDS
 //     through a volatile pointer -- otherwise the compiler notices that half of it is already in a register and assembles
 //     the pair with v_mov, which costs as much as the arithmetic it saves.  Needs radius % H == 0.
-//   VAR 0: scalar v_add_f32 + v_fmac_f32 per output and tap (any radius).
+//   VAR 0: scalar v_add_f32 + v_fmac_f32 per output and tap (any radius).  VOP2 float32 on VGPR operands issues about
+//     twice as fast as the packed instructions (tools/ubench/valu_rate.hip: 109 vs 104 TFLOP/s for this add+fma mix), so
+//     the two variants run within a few percent of each other.
 // Error vs the exact pass: every term is non-negative, so |fast - exact| <= ((1+u)^(r+3) - 1) * exact, u = 2^-24
 // (tap rounding + pair-sum rounding + at most r+1 FMA roundings); see k_argmax_certify for how the bound is used.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
