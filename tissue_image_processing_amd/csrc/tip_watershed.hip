@@ -263,37 +263,56 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
     const WCell n0 = tv.cell[q0], n1 = tv.cell[q1], n2 = tv.cell[q2], n3 = tv.cell[q3];
     const unsigned long long s0 = n0.st, s1 = n1.st, s2 = n2.st, s3 = n3.st;
     const int l0 = st_lab(s0), l1 = st_lab(s1), l2 = st_lab(s2), l3 = st_lab(s3);
-    if (!(l0 > 0 || l1 > 0 || l2 > 0 || l3 > 0)) return d;
+    // (no early-out for "no labelled neighbour": cells on the work list always have one, and the rule below yields
+    // "no decision" anyway if they did not)
     const double v0 = n0.v, v1 = n1.v, v2 = n2.v, v3 = n3.v, vc = tv.cell[c].v;
     const int g0 = gc - tv.X, g1 = gc - 1, g2 = gc + 1, g3 = gc + tv.X;
     int s_lab = 0, pull_lab = 0, pull_ti = 0;
     bool conflict = false, has_pull = false;
     double pull_tv = 0.0;
     unsigned early_u = 0, und = 0;   // bit k: undecided neighbour k (that could pop before this cell)
+    // straight-line, select-based evaluation of the four neighbours: this code runs with few active lanes and every
+    // divergent branch costs scalar exec-mask bookkeeping -- the kernel is bound by scalar/branch issue, not by math
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const unsigned long long sq = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
         const int l = k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));
         const int gq = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
-        double tq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
-        if (l == LINE_LAB) continue;
-        int ti = gq;
-        if (l > 0) ti = st_tref(sq);   // (tq already is the pop-time value of a labelled cell)
+        const double tq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));   // a labelled cell's slot holds its pop-time value
+        const bool lab = l > 0, undq = l == 0;
+        const int ti = lab ? st_tref(sq) : gq;
         const bool before = tq < vc || (tq == vc && ti < gc);
-        if (l > 0) {
-            if (before) {
-                if (s_lab == 0) s_lab = l;
-                else if (s_lab != l) conflict = true;
-            } else if (!has_pull || tq < pull_tv || (tq == pull_tv && ti < pull_ti)) {
-                has_pull = true; pull_tv = tq; pull_ti = ti; pull_lab = l;
-            }
-        } else {
-            und |= 1u << k;
-            if (before) early_u |= 1u << k;
+        const bool first = lab & before;                       // labelled before this cell pops
+        conflict |= first & (s_lab != 0) & (s_lab != l);
+        s_lab = (first & (s_lab == 0)) ? l : s_lab;
+        const bool later = lab & !before;                      // a possible puller
+        const bool better = later & (!has_pull | (tq < pull_tv) | ((tq == pull_tv) & (ti < pull_ti)));
+        has_pull |= later;
+        pull_tv = better ? tq : pull_tv;
+        pull_ti = better ? ti : pull_ti;
+        pull_lab = better ? l : pull_lab;
+        und |= undq ? (1u << k) : 0u;
+        early_u |= (undq & before) ? (1u << k) : 0u;
+    }
+    if (!certs) {
+        // the everyday round, branch-free: nothing is decided while an undecided neighbour could pop earlier
+        unsigned blk = 0;   // undecided neighbours that could still be labelled before the pull
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double vq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
+            const int gq = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+            const bool after_pull = (pull_tv < vq) | ((pull_tv == vq) & (pull_ti < gq));
+            blk |= (((und >> k) & 1u) != 0u) & !after_pull ? 1u : 0u;
         }
+        const bool quiet = early_u == 0;
+        const bool ok_normal = (s_lab != 0) & quiet;
+        const bool ok_pull = (s_lab == 0) & has_pull & quiet & (blk == 0);
+        d.lab = ok_normal ? (conflict ? LINE_LAB : s_lab) : (ok_pull ? pull_lab : 0);
+        d.ti = ok_normal ? gc : pull_ti;
+        d.tv = ok_normal ? vc : pull_tv;
+        return d;
     }
     if (early_u) {
-        if (!certs) return d;
 #pragma unroll 1
         for (int k = 0; k < 4; ++k)
             if ((early_u >> k) & 1u) {
@@ -401,45 +420,44 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         const int n = s_n[cur];
         if (n == 0) break;
         my_rounds++;
-        // at most 4 list entries per thread (n <= WT*WT = 4 * WS_THREADS); static indices keep cc/dec in registers
-        int cc[4];
-        Decision dec[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = threadIdx.x + j * WS_THREADS;
-            cc[j] = -1;
-            dec[j].lab = 0; dec[j].ti = 0; dec[j].tv = 0.0;
-            if (i < n) {
-                const int c = slist[cur][i];
-                if (st_lab(cells[c].st) == 0) { my_evals++; cc[j] = c; dec[j] = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
-                // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
-            }
-        }
-        __syncthreads();  // every read of this round is done
         if (threadIdx.x == 0) { s_n[cur ^ 1] = 0; s_any = 0; }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = cc[j];
-            if (c < 0) continue;
-            if (dec[j].lab == 0) {  // still waiting: stays on the frontier
-                slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
-                continue;
+        // The list is worked off in chunks of one entry per thread, each chunk committed before the next is evaluated
+        // (decisions are certified on the states they read, so committing earlier is just a finer round).  One inlined
+        // copy of the flood rule instead of four keeps the kernel small -- it is branchy scalar-heavy code and used to
+        // overflow the instruction cache -- and almost every round has a single chunk anyway.
+#pragma unroll 1
+        for (int base = 0; base < n; base += WS_THREADS) {
+            const int i = base + threadIdx.x;
+            int c = -1;
+            Decision dec{0, 0, 0.0};
+            if (i < n) {
+                const int c0 = slist[cur][i];
+                if (st_lab(cells[c0].st) == 0) { my_evals++; c = c0; dec = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
+                // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
             }
-            cells[c].st = pack_st(dec[j].lab, dec[j].ti); cells[c].v = dec[j].tv;
-            s_any = 1;
-            atomicAdd(&s_chg, 1);
-            if (dec[j].lab > 0) {
+            __syncthreads();  // every read of this chunk is done
+            if (c >= 0) {
+                if (dec.lab == 0) {  // still waiting: stays on the frontier
+                    slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
+                } else {
+                    cells[c].st = pack_st(dec.lab, dec.ti); cells[c].v = dec.tv;
+                    s_any = 1;
+                    atomicAdd(&s_chg, 1);
+                    if (dec.lab > 0) {
+                        const int cy = c / WL, cx = c - cy * WL;   // c is interior: a neighbour is interior unless c is on that edge
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
-                    const int qy = q / WL, qx = q - qy * WL;
-                    if (qy >= WH && qy < WH + WT && qx >= WH && qx < WH + WT && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
-                        slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                        for (int k = 0; k < 4; ++k) {
+                            const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+                            const bool inside = k == 0 ? cy > WH : (k == 1 ? cx > WH : (k == 2 ? cx < WH + WT - 1 : cy < WH + WT - 1));
+                            if (inside && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
+                                slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                        }
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         cur ^= 1;
         if (s_any) { certs = false; continue; }
         if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
