@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/sq; mkdir -p $out
 A="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY"
-B="SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_ANY"
+B="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --pmc $A --output-format csv -d $out/a -o a -- python3 bench.py --workload ${1:-projection} --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > $out/a.json 2> $out/a.err || { tail -5 $out/a.err; exit 1; }
 rocprofv3 --kernel-trace --pmc $B --output-format csv -d $out/b -o b -- python3 bench.py --workload ${1:-projection} --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > $out/b.json 2> $out/b.err || { tail -5 $out/b.err; exit 1; }
 python3 - $A $B <<'PY'
