@@ -5,7 +5,7 @@
  * relies on (scipy.ndimage 1.7.1 / scikit-image 0.18.3 semantics at the
  * reference's call sites).  It is pinned against golden
  * vectors produced by running the reference itself (tools/make_goldens.py ->
- * tests/golden/*.npz).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * the .npz files under tests/golden).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product path never does.
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
