@@ -387,42 +387,67 @@ static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int 
 // recomputed in exact scipy arithmetic from the z-passed volume, for the candidate planes only.
 #define CERT_EPS (320.0f * 5.9604644775390625e-8f)
 
+// four adjacent pixels per thread (one float4 per plane): enough bytes in flight to stream the score volume
 __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict__ score, int Z, long P, int *__restrict__ best_z,
                                                         int *__restrict__ unc_list, int *__restrict__ unc_count)
 {
     __shared__ int s_cnt[4], s_base;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool certain = true;
-    if (p < P) {
-        float b1 = score[p], b2 = -1.f;
-        int z1 = 0;
-        for (int z = 1; z < Z; ++z) {
-            const float s = score[(long)z * P + p];
-            if (s > b1) { b2 = b1; b1 = s; z1 = z; }
-            else if (s > b2) b2 = s;
+    const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const bool vec = p0 + 4 <= P && (P & 3) == 0;
+    float b1[4], b2[4];
+    int z1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { b1[k] = -1.f; b2[k] = -1.f; z1[k] = 0; }
+    if (p0 < P) {
+        for (int z = 0; z < Z; ++z) {
+            float v[4];
+            if (vec) {
+                const float4 f = *reinterpret_cast<const float4 *>(score + (long)z * P + p0);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = p0 + k < P ? score[(long)z * P + p0 + k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // scores are >= 0: the -1 start makes plane 0 the first maximum
+                if (v[k] > b1[k]) { b2[k] = b1[k]; b1[k] = v[k]; z1[k] = z; }
+                else if (v[k] > b2[k]) b2[k] = v[k];
+            }
         }
-        best_z[p] = z1;
+    }
+    unsigned unc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (p0 + k >= P) continue;
+        best_z[p0 + k] = z1[k];
         // b1 == 0: every plane is exactly zero in the fast pass, hence (no underflow for uint16-derived data) in the exact one
-        certain = (b1 == 0.f) || (Z == 1) || (b1 * (1.f - CERT_EPS) > b2 * (1.f + CERT_EPS) + 1e-30f);
+        const bool certain = (b1[k] == 0.f) || (Z == 1) || (b1[k] * (1.f - CERT_EPS) > b2[k] * (1.f + CERT_EPS) + 1e-30f);
+        if (!certain) unc |= 1u << k;
     }
     // append with one atomic per block (not per pixel: same-address atomics serialise in L2)
-    const unsigned long long m = __ballot(!certain);
+    const int mine = __popc(unc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = __popcll(m);
+    int incl = mine;   // inclusive prefix sum over the wave
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_cnt[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         s_base = tot ? atomicAdd(unc_count, tot) : 0;
     }
     __syncthreads();
-    if (!certain) {
-        int off = s_base + __popcll(m & ((1ULL << lane) - 1ULL));
+    if (mine) {
+        int off = s_base + incl - mine;
         for (int w = 0; w < wave; ++w) off += s_cnt[w];
-        unc_list[off] = (int)p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((unc >> k) & 1u) unc_list[off++] = (int)(p0 + k);
     }
 }
 
-// one block per uncertified pixel: exact score of every candidate plane, then first-maximum argmax among them
 constexpr int FIX_UL = 16;
 __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restrict__ zvol, const float *__restrict__ score, int Z, int Y,
                                                           int X, Taps taps, const int *__restrict__ unc_list,
@@ -433,7 +458,13 @@ __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restric
     __shared__ float sexact[64];
     __shared__ int s_z;
     const int r = taps.n >> 1;  // 120
-    for (int u = blockIdx.x; u < *unc_count; u += gridDim.x) {
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is in raster
+    // order and neighbouring pixels read almost the same window of the volume, so every XCD gets one contiguous eighth
+    // of the list instead of every eighth entry.
+    const int total = *unc_count, xcd = blockIdx.x & 7, per = (total + 7) / 8;
+    for (int sl = blockIdx.x >> 3; sl < per; sl += gridDim.x >> 3) {
+        const int u = xcd * per + sl;
+        if (u >= total) break;
         const int p = unc_list[u];
         const int y = p / X, x = p - y * X;
         const long P = (long)Y * X;
@@ -587,7 +618,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
             if ((rc = launch_fast<2>(cx, (const float *)A, D, Zs, Y, X, f30))) return rc;
         }
         TIP_HIP(hipMemsetAsync(uncn, 0, sizeof(int), c.stream));
-        TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(P, 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
+        TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(cdiv(P, 4), 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
         TIP_LAUNCH("argmax_exact_fix", k_argmax_exact_fix, dim3(8192), dim3(256), 0, (const float *)B, (const float *)D, Zs, Y, X,
                    k30, (const int *)unc, (const int *)uncn, bestz);
         TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
