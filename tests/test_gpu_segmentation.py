@@ -137,6 +137,31 @@ def test_watershed_vs_oracle_synthetic_frame(env):
     assert mism == 0
 
 
+def test_headline_frame_segmentation_and_tables_bit_exact(env):
+    """BASELINE's headline frame (2048x2048x30, C=2): the classical segmentation of the GPU projection and the cell
+    tables on it, against the oracle's exact heap flood at FULL size (about 20 s of CPU)."""
+    bim, _, _, orc = env
+    from tissue_image_processing_amd import synthetic, _segmentation as seg
+    from tissue_image_processing_amd import surface_projection as sp
+    st = synthetic.make_stack(30, 2048, 2048, seed=100)        # bench.py's frame
+    proj, _ = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    zo = proj[0]
+    out, flags = seg.watershed_segmentation(zo, 0.03, 3, 3, return_flags=True)
+    ref = orc.watershed_segmentation(zo, 0.03, 3, 3)
+    assert int(ref.max()) > 4000
+    mism = int((out != ref).sum())
+    print("headline frame: %d labels, flags %d (fallback steps %d), mismatches %d" % (ref.max(), flags & 3, flags >> 2, mism))
+    assert mism == 0
+    got = seg.regionprops_arrays(out)
+    want = orc.regionprops(ref)
+    for k in ("area", "bbox", "cy", "cx"):
+        np.testing.assert_array_equal(got[k], want[k])
+    np.testing.assert_allclose(got["perimeter"], want["perimeter"], rtol=1e-13)
+    gp = seg.neighbor_pairs(out)
+    wp = orc.neighbor_pairs(ref)
+    assert set(map(tuple, np.asarray(gp).tolist())) == set(map(tuple, np.asarray(wp).tolist()))
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_cellinfo_golden(env, golden, tag):
     _, seg, ti, _ = env
