@@ -573,7 +573,7 @@ __global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long 
 // each one is finished by ONE wave running the serial rule -- commit the component's smallest pop time, repeat -- on an
 // LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / global-minimum fallback.
 constexpr int END_CAP = 512;
-constexpr int WS_EARLY_BURST = 2;   // the first endgame runs after this many tile bursts, without waiting for a stall
+constexpr int WS_EARLY_BURST = 1;   // the first endgame runs after this many tile bursts (the first has 10 launches), without waiting for a stall
 constexpr int WS_END_STEPS = 32;    // serial commits per component and endgame: clears the stuck seeds, the rest is tile work
 
 struct SameU {
@@ -899,12 +899,14 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         int endgames = 0;
         int burst_no = 0;
         bool early_done = false;
+        int post_end_burst = -1;   // index of the first burst after the early endgame
         const int dbg = getenv("TIP_WS_DEBUG") ? 1 : 0;
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             // tile launches go out in bursts with ONE host check per burst (a launch whose tiles are all inactive costs
-            // ~15 us, a host round trip ~50 us): 6 launches first, then 4, then 2 at a time
-            const int burst = wide ? 1 : (burst_no == 0 ? 6 : (burst_no == 1 ? 4 : 2));
+            // ~15 us, a host round trip ~50 us): 10 launches first (the bulk); after the early endgame its dependents need
+            // ~8 more launches (measured), sent as one burst; then 2 at a time
+            const int burst = wide ? 1 : (burst_no == 0 ? 10 : (burst_no == post_end_burst ? 8 : 2));
             burst_no++;
             for (int rep = 0; rep < burst; ++rep) {
                 if (rep) ++iter;
@@ -928,13 +930,14 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // The first two bursts do the bulk; what is left then are a few thousand pixels in long dependency chains
             // that would cost one (latency-bound) launch per tile border crossed: replay them serially per component
             // right away instead of waiting for the tile rounds to stall.
-            // (measured on 2048^2 frames: after burst 2 with 32 serial steps per component 2.9 ms per frame; after burst 1
-            // 4.0 ms, after burst 3 3.05 ms, 512 steps 3.7 ms, no early endgame 3.6 ms)
+            // (measured on 2048^2 frames: after 10 launches with 32 serial steps per component 2.9 ms per frame; after 6
+            // launches 4.0 ms, after 12 3.05 ms, 512 steps 3.7 ms, no early endgame 3.6 ms)
             const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !getenv("TIP_WS_NO_ENDGAME");
             if (h.changed > 0 && !early_endgame) { wide = false; continue; }
             const bool quiescent = h.changed == 0;
-            long und_total = 0, front_total = 0;
-            {
+            long und_total = 1, front_total = 1;
+            if (quiescent || !early_endgame) {   // (the early endgame runs regardless: it finds "nothing left" itself)
+                und_total = 0; front_total = 0;
                 std::vector<int> hu((size_t)2 * ntiles);
                 TIP_HIP(hipMemcpyAsync(hu.data(), tile_und, (size_t)2 * ntiles * 4, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
@@ -949,6 +952,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             if (front_total == 0 && !wide && quiescent) break;
             if (!wide_after_endgame && !getenv("TIP_WS_NO_ENDGAME")) {   // (env: test hook that exercises the fallback machinery)
                 // serial rule on every connected component of undecided pixels that fits one wave's LDS copy
+                if (!early_done) post_end_burst = burst_no;
                 early_done = true;
                 SameU su{st};
                 if ((rc = uf_components(su, parent, Y, X))) return rc;
