@@ -165,8 +165,13 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
 //   VAR 0: scalar v_add_f32 + v_fmac_f32 per output and tap (any radius).  VOP2 float32 on VGPR operands issues about
 //     twice as fast as the packed instructions (tools/ubench/valu_rate.hip: 109 vs 104 TFLOP/s for this add+fma mix), so
 //     the two variants run within a few percent of each other.
-// Error vs the exact pass: every term is non-negative, so |fast - exact| <= ((1+u)^(r+3) - 1) * exact, u = 2^-24
-// (tap rounding + pair-sum rounding + at most r+1 FMA roundings); see k_argmax_certify for how the bound is used.
+// Error vs the exact pass: every term is non-negative.  The taps are summed in partial sums of at most FAST_SEG taps
+// that are flushed into a running total, so a term sees at most FAST_SEG + 1 FMA roundings (its partial sum, the centre
+// term included), one tap rounding, one pair-sum rounding and at most ceil(r / 8) + 1 roundings of the running total:
+//     |fast - exact| <= ((1+u)^(FAST_SEG + 3 + ceil(r/8) + 1) - 1) * exact,   u = 2^-24
+// i.e. 35 u for r = 120 and 36 u at the largest radius (a single running sum would be 123 u); see k_argmax_certify for
+// how the bound is used.
+constexpr int FAST_SEG = 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int AXIS, int TO, int NW, int R, int VAR>
@@ -214,6 +219,10 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
                     L[i] = ctr[(i - r) * LS];
                     Rr[i] = ctr[(i + r) * LS];
                 }
+                float tot[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) tot[i] = 0.f;
+                int seg = 0;
 #pragma unroll R
                 for (int d = r; d >= 1; --d) {
                     const float w = wl[r - d];
@@ -225,13 +234,20 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
 #pragma unroll
                     for (int i = R - 1; i > 0; --i) Rr[i] = Rr[i - 1];
                     Rr[0] = ctr[(d - 1) * LS];
+                    if (++seg == FAST_SEG) {   // short partial sums: see the error bound above k_argmax_certify
+                        seg = 0;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) { tot[i] += acc[i]; acc[i] = 0.f; }
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < R; ++i) res[i] = acc[i];
+                for (int i = 0; i < R; ++i) res[i] = tot[i] + acc[i];
             } else {
-                f32x2 acc[H], L[H], Rr[H];
+                static_assert(H <= FAST_SEG, "partial sums must stay within the certified bound");
+                f32x2 acc[H], L[H], Rr[H], tot[H];
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
+                    tot[j] = f32x2{0.f, 0.f};
                     acc[j] = f32x2{ctr[j * LS], ctr[(j + H) * LS]} * wc;
                     L[j] = f32x2{ctr[(j - r) * LS], ctr[(j + H - r) * LS]};
                     Rr[j] = f32x2{ctr[(j + r) * LS], ctr[(j + H + r) * LS]};
@@ -256,9 +272,12 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
                         L[H - 1] = f32x2{q[(H - d) * LS], q[(2 * H - d) * LS]};
                         Rr[0] = f32x2{q[(d - 1) * LS], q[(H + d - 1) * LS]};
                     }
+                    // short partial sums (H <= FAST_SEG taps each): see the error bound above k_argmax_certify
+#pragma unroll
+                    for (int j = 0; j < H; ++j) { tot[j] += acc[j]; acc[j] = f32x2{0.f, 0.f}; }
                 }
 #pragma unroll
-                for (int j = 0; j < H; ++j) { res[j] = acc[j].x; res[j + H] = acc[j].y; }
+                for (int j = 0; j < H; ++j) { res[j] = tot[j].x; res[j + H] = tot[j].y; }
             }
         }
         if (STAGED) {

@@ -380,12 +380,14 @@ static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int 
 // ---- certified argmax --------------------------------------------------------------------------------------------------
 // The sigma-30 score is used for ONE thing: chosen_z = argmax_z(score) (sp.py:55-61).  So the score itself need not be
 // exact -- only the argmax must be.  The fast passes (k_corr_long_fast) give S~ with |S~ - S| <= EPS * S for the exact
-// float32 score S: each fast pass is within a = (1+u)^123 - 1 of the real-number sum and scipy's pass within 1.0001u of it
-// (u = 2^-24, all terms non-negative), two passes compose to 2a + 2.1u < 249u; EPS = 320u leaves > 25 % headroom.
+// float32 score S: each fast pass is within a = (1+u)^36 - 1 of the real-number sum (short partial sums, see tip_corr.h)
+// and scipy's pass within 1.0001u of it (u = 2^-24, all terms non-negative), two passes compose to 2a + 2.1u < 74.2u;
+// EPS = 96u leaves 29 % headroom.  (With one running sum per output a was 123u and EPS 320u: the uncertified pixels --
+// and the cost of the exact fix-up -- scale with EPS.)
 // A pixel is certified when its best fast score beats every other plane by more than both error bars; the few that
-// are not (top two planes closer than ~4e-5 relative: the lines where the surface crosses between planes) are
+// are not (top two planes closer than ~1.2e-5 relative: the lines where the surface crosses between planes) are
 // recomputed in exact scipy arithmetic from the z-passed volume, for the candidate planes only.
-#define CERT_EPS (320.0f * 5.9604644775390625e-8f)
+#define CERT_EPS (96.0f * 5.9604644775390625e-8f)
 
 // four adjacent pixels per thread (one float4 per plane): enough bytes in flight to stream the score volume
 __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict__ score, int Z, long P, int *__restrict__ best_z,
