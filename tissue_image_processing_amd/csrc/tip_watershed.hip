@@ -302,7 +302,7 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
             const double vq = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
             const int gq = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
             const bool after_pull = (pull_tv < vq) | ((pull_tv == vq) & (pull_ti < gq));
-            blk |= (((und >> k) & 1u) != 0u) & !after_pull ? 1u : 0u;
+            blk |= ((((und >> k) & 1u) != 0u) & !after_pull) ? 1u : 0u;
         }
         const bool quiet = early_u == 0;
         const bool ok_normal = (s_lab != 0) & quiet;
