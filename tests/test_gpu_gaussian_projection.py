@@ -215,3 +215,21 @@ def test_projection_headline_frame_vs_oracle(mods):
     rproj, rzmap = orc.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
     assert int((zmap != rzmap).sum()) == 0
     np.testing.assert_array_equal(proj, rproj)
+
+
+def test_scalar_fast_pass_variant_gives_the_same_zmap(mods, monkeypatch):
+    """The scalar fast-pass variant (used when the score radius is not a multiple of 8) is selected here through the
+    tuning hook; certification makes the z-map independent of which fast variant produced the approximate score."""
+    _, sp, _ = mods
+    from tissue_image_processing_amd import synthetic
+    st = synthetic.make_stack(12, 512, 768, seed=77)
+    proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    monkeypatch.setenv("TIP_FAST_CFG", "1616,1616")
+    proj_s, zmap_s = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    monkeypatch.delenv("TIP_FAST_CFG")
+    monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
+    proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    np.testing.assert_array_equal(zmap, zmap_e)
+    np.testing.assert_array_equal(zmap_s, zmap_e)
+    np.testing.assert_array_equal(proj, proj_e)
+    np.testing.assert_array_equal(proj_s, proj_e)
