@@ -99,6 +99,7 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
     from tissue_image_processing_amd import movie, synthetic
     Y, X, Z = args.size
     T = args.steps * world
+    use_dist = world > 1
     sites_t, is_hc = synthetic.make_movie_sites(Y, X, T, seed=5)
     mine = list(range(rank, T, world))
     stacks = {t: synthetic.make_stack(Z, Y, X, seed=200 + t, sites=sites_t[t], is_hc=is_hc) for t in mine}
@@ -116,7 +117,7 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -156,7 +157,9 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TIP_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1) walks the RCCL process-group path on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("TIP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -276,7 +279,7 @@ def main():
             w.wait()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -297,7 +300,7 @@ def main():
     workers[0].submit(("steps", iter(range(iso_steps)))); workers[0].wait()
     workers[0].submit(("prof", "off")); workers[0].wait()
     iso_report = dict(workers[0].report)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -377,7 +380,7 @@ def main():
                                    "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle, %.1f s, "
                                              "scaled by pixel count" % (Ys, Xs, Z, scale, dt)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
