@@ -40,7 +40,7 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
         # global iteration over the same frame, so the per-launch figure is the per-frame one
         "ws_tiles": P * 12, "ws_tiles_wide": P * 12,
         "regionprops": P * 4, "neighbor_pairs": P * 4, "local_threshold": 2 * P * 8,
-        "corr_generic_y_f64": 2 * P * 8, "corr_generic_x_f64": 2 * P * 8,
+        "corr_generic_y_f64": 2 * P * 8, "corr_generic_x_f64": 2 * P * 8, "yslide_r12_f64": 2 * P * 8, "xslide_r12_f64": 2 * P * 8,
     }
     return table.get(kernel)
 

@@ -1,6 +1,7 @@
 // tip_gauss.hip -- separable Gaussian entry points (scipy.ndimage.gaussian_filter(mode='nearest'),
 // reference call site bim.py:389 via sp.py:37,55,70,71 and ti.py:142).
 #include "tip_corr.h"
+#include "tip_slide.h"
 
 namespace tip {
 
@@ -54,7 +55,21 @@ int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, i
     }
     if (use_long) return corr_long_f32((const float *)in, (float *)out, Z, Y, X, axis, t);
     if (dtype == 0) return corr_generic<float>((const float *)in, (float *)out, Z, Y, X, axis, t);
-    if (dtype == 1) return corr_generic<double>((const double *)in, (double *)out, Z, Y, X, axis, t);
+    if (dtype == 1) {
+        // radius 12 (sigma 3, the watershed's default blur, bim.py:474) along y / x: register-sliding kernels, each
+        // input loaded once per thread instead of 25 times through the caches
+        if (r == 12 && axis == 1) {
+            TIP_LAUNCH("yslide_r12_f64", (k_ypass_slide<double, 12, 2>), dim3(cdiv(X, 256), cdiv(Y, 50), Z), dim3(256), 0,
+                       (const double *)in, (double *)out, Y, X, t);
+            return TIP_OK;
+        }
+        if (r == 12 && axis == 2) {
+            TIP_LAUNCH("xslide_r12_f64", (k_xpass_slide<double, 12>), dim3(cdiv(cdiv(X, 8), 256), Y, Z), dim3(256), 0,
+                       (const double *)in, (double *)out, Y, X, t);
+            return TIP_OK;
+        }
+        return corr_generic<double>((const double *)in, (double *)out, Z, Y, X, axis, t);
+    }
     return fail(TIP_ERR_ARG, "correlate1d: dtype %d", dtype);
 }
 

@@ -590,9 +590,9 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         // P3: (0.5, 1, 1) and P4's z pass with register-sliding kernels (each input loaded once per thread)
         Src4U16Clip su{ref, airyscan, &clip->p95, &clip->has};
         TIP_LAUNCH("zpass_u16clip_x4", (k_zpass_r2_x4<Src4U16Clip>), dim3(cdiv(P / 4, 256)), dim3(256), 0, su, A, Zs, P, k05);
-        TIP_LAUNCH("ypass_slide_r4", (k_ypass_slide<4, 4>), dim3(cdiv(X, 256), cdiv(Y, 36), Zs), dim3(256), 0, (const float *)A, B, Y,
+        TIP_LAUNCH("ypass_slide_r4", (k_ypass_slide<float, 4, 4>), dim3(cdiv(X, 256), cdiv(Y, 36), Zs), dim3(256), 0, (const float *)A, B, Y,
                    X, k1);
-        TIP_LAUNCH("xpass_slide_r4", (k_xpass_slide<4>), dim3(cdiv(cdiv(X, 8), 256), Y, Zs), dim3(256), 0, (const float *)B, A, Y, X,
+        TIP_LAUNCH("xpass_slide_r4", (k_xpass_slide<float, 4>), dim3(cdiv(cdiv(X, 8), 256), Y, Zs), dim3(256), 0, (const float *)B, A, Y, X,
                    k1);
         Src4F32 sf{A};
         TIP_LAUNCH("zpass_f32_x4", (k_zpass_r2_x4<Src4F32>), dim3(cdiv(P / 4, 256)), dim3(256), 0, sf, B, Zs, P, k05);

@@ -81,15 +81,15 @@ __global__ void __launch_bounds__(256) k_zpass_r2_x4(Src src, float *__restrict_
 }
 
 // ---- y pass: one thread per x, slides down a segment of SEG*(2R+1) outputs with a rotating register window ---------------
-template <int R, int SEG>
-__global__ void __launch_bounds__(256) k_ypass_slide(const float *__restrict__ in, float *__restrict__ out, int Y, int X, Taps taps)
+template <typename T, int R, int SEG>
+__global__ void __launch_bounds__(256) k_ypass_slide(const T *__restrict__ in, T *__restrict__ out, int Y, int X, Taps taps)
 {
     constexpr int W = 2 * R + 1;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= X) return;
     const int y0 = blockIdx.y * (SEG * W);
-    const float *src = in + (long)blockIdx.z * Y * X + x;
-    float *dst = out + (long)blockIdx.z * Y * X + x;
+    const T *src = in + (long)blockIdx.z * Y * X + x;
+    T *dst = out + (long)blockIdx.z * Y * X + x;
     double win[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) win[i] = (double)src[(long)clampi(y0 - R + i, 0, Y - 1) * X];
@@ -101,44 +101,46 @@ __global__ void __launch_bounds__(256) k_ypass_slide(const float *__restrict__ i
             double tmp = win[(o + R) % W] * taps.w[R];
 #pragma unroll
             for (int d = R; d >= 1; --d) tmp += (win[(o + R - d) % W] + win[(o + R + d) % W]) * taps.w[R - d];
-            if (y < Y) dst[(long)y * X] = (float)tmp;
+            if (y < Y) dst[(long)y * X] = (T)tmp;
             win[o % W] = (double)src[(long)clampi(y + R + 1, 0, Y - 1) * X];  // the slot that just left the window
         }
     }
 }
 
 // ---- x pass: 8 consecutive outputs per thread from 8 + 2R inputs (aligned float4 loads when possible) --------------------
-template <int R>
-__global__ void __launch_bounds__(256) k_xpass_slide(const float *__restrict__ in, float *__restrict__ out, int Y, int X, Taps taps)
+template <typename T, int R>
+__global__ void __launch_bounds__(256) k_xpass_slide(const T *__restrict__ in, T *__restrict__ out, int Y, int X, Taps taps)
 {
     constexpr int N = 8 + 2 * R;
+    constexpr bool F32 = sizeof(T) == 4;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const long row = (long)blockIdx.z * Y + blockIdx.y;
     if (x0 >= X) return;
-    const float *src = in + row * X;
-    float v[N];
-    if (x0 - R >= 0 && x0 + 8 + R <= X && (X & 3) == 0 && (R & 3) == 0) {
+    const T *src = in + row * X;
+    T v[N];
+    if (F32 && x0 - R >= 0 && x0 + 8 + R <= X && (X & 3) == 0 && (R & 3) == 0) {
 #pragma unroll
         for (int i = 0; i < N / 4; ++i) {
-            const float4 f = *reinterpret_cast<const float4 *>(src + x0 - R + 4 * i);
-            v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+            const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + x0 - R + 4 * i);
+            v[4 * i] = (T)f.x; v[4 * i + 1] = (T)f.y; v[4 * i + 2] = (T)f.z; v[4 * i + 3] = (T)f.w;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = src[clampi(x0 - R + i, 0, X - 1)];
     }
-    float o[8];
+    T o[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         double tmp = (double)v[k + R] * taps.w[R];
 #pragma unroll
         for (int d = R; d >= 1; --d) tmp += ((double)v[k + R - d] + (double)v[k + R + d]) * taps.w[R - d];
-        o[k] = (float)tmp;
+        o[k] = (T)tmp;
     }
-    float *dst = out + row * X + x0;
-    if (x0 + 8 <= X && (X & 3) == 0) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    T *dst = out + row * X + x0;
+    if (F32 && x0 + 8 <= X && (X & 3) == 0) {
+        float *df = reinterpret_cast<float *>(dst);
+        *reinterpret_cast<float4 *>(df) = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        *reinterpret_cast<float4 *>(df + 4) = make_float4((float)o[4], (float)o[5], (float)o[6], (float)o[7]);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
