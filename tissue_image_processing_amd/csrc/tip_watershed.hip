@@ -592,11 +592,21 @@ __global__ void __launch_bounds__(256) k_end_count(const unsigned long long *__r
     if (u) atomicAdd(&cnt[parent[i]], 1);
 }
 
+// every component root reserves its slice of the cell buffer and its slot in the root list with two atomics (a few
+// hundred to a few thousand roots per frame: cheaper than two 4 M-element scans; the order of components is irrelevant)
+__global__ void __launch_bounds__(256) k_end_offsets(const int *__restrict__ cnt, const int *__restrict__ isroot,
+                                                     int *__restrict__ off, int *__restrict__ roots, int *__restrict__ counters, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !isroot[i]) return;
+    off[i] = atomicAdd(&counters[1], cnt[i]);
+    roots[atomicAdd(&counters[0], 1)] = (int)i;
+}
+
 __global__ void __launch_bounds__(256) k_end_scatter(const unsigned long long *__restrict__ st, const int *__restrict__ parent,
                                                      const int *__restrict__ off, int *__restrict__ cursor,
                                                      int *__restrict__ cells, int *__restrict__ slot,
-                                                     const int *__restrict__ isroot, const int *__restrict__ rootrank,
-                                                     int *__restrict__ roots, long n)
+                                                     long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -605,7 +615,6 @@ __global__ void __launch_bounds__(256) k_end_scatter(const unsigned long long *_
     const int k = atomicAdd(&cursor[r], 1);
     cells[off[r] + k] = (int)i;
     slot[i] = k;
-    if (isroot[i]) roots[rootrank[i]] = (int)i;
 }
 
 // One wave replays the serial flood on one component.  Every cell caches its candidate pop time
@@ -959,16 +968,16 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));      // cnt
                 TIP_LAUNCH("ws_end_count", k_end_count, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
                            (const int *)parent, flag, isroot, n);
-                int *off = rank;                                            // exclusive scan of component sizes
-                if ((rc = exclusive_scan_i32(flag, off, n, nullptr))) return rc;
-                int *rootrank = ws.get<int>(n), *cursor = ws.get<int>(n), *cellsbuf = ws.get<int>(n), *slot = ws.get<int>(n),
-                    *roots = ws.get<int>(n), *ncomp_d = ws.get<int>(1);
-                if (!rootrank || !cursor || !cellsbuf || !slot || !roots || !ncomp_d) return TIP_ERR_NOMEM;
-                if ((rc = exclusive_scan_i32(isroot, rootrank, n, ncomp_d))) return rc;
+                int *off = rank;                                            // start of every component's cells in cellsbuf
+                int *cursor = ws.get<int>(n), *cellsbuf = ws.get<int>(n), *slot = ws.get<int>(n), *roots = ws.get<int>(n),
+                    *ncomp_d = ws.get<int>(2);                              // [0] components, [1] cells
+                if (!cursor || !cellsbuf || !slot || !roots || !ncomp_d) return TIP_ERR_NOMEM;
+                TIP_HIP(hipMemsetAsync(ncomp_d, 0, 2 * sizeof(int), s));
+                TIP_LAUNCH("ws_end_offsets", k_end_offsets, dim3(cdiv(n, 256)), dim3(256), 0, (const int *)flag, (const int *)isroot,
+                           off, roots, ncomp_d, n);
                 TIP_HIP(hipMemsetAsync(cursor, 0, n * sizeof(int), s));
                 TIP_LAUNCH("ws_end_scatter", k_end_scatter, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
-                           (const int *)parent, (const int *)off, cursor, cellsbuf, slot, (const int *)isroot,
-                           (const int *)rootrank, roots, n);
+                           (const int *)parent, (const int *)off, cursor, cellsbuf, slot, n);
                 int ncomp = 0;
                 TIP_HIP(hipMemcpyAsync(&ncomp, ncomp_d, sizeof(int), hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
