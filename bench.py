@@ -5,6 +5,11 @@ One "step" = one pass of the hot path over one synthetic 2048x2048x30 (C=2, uint
 resident in HBM: surface projection (sp.py:17-85) -> watershed_segmentation (bim.py:446-476) -> cell tables
 (ti.py:880-909).  One process per GPU; frames are independent units, so N GPUs process N frames per step with no
 data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
+
+`value` is the classical-segmentation variant (`config.workload` says so).  BASELINE.json's config 3 names the U-Net
+variant (projection -> U-Net (pl.py:124-199) -> threshold / closing / watershed tail -> cell tables): the default run
+times that too, right after the classical leg, and reports it in the same line under "unet" with its MFMA roofline
+(`--workload unet` makes it the headline instead; `--no-unet-leg` skips it).
 """
 import argparse
 import ctypes
@@ -77,19 +82,36 @@ def algorithmic_dp_ops(kernel, Z, Y, X):
     return None
 
 
-def cpu_baseline(sample_yx, Z, workload):
-    """Times the CPU oracle (a C/numpy port of the reference path, single thread like scipy.ndimage) on a crop."""
+def cpu_baseline_worker(Ys, Xs, Z, workload):
+    """One CPU-baseline sample: the C/numpy oracle (a port of the reference path, single thread like scipy.ndimage) on a
+    crop of the workload; prints the seconds it took."""
     from oracle import oracle as orc
     from tissue_image_processing_amd import synthetic
-    Ys, Xs = sample_yx
     st = synthetic.make_stack(Z, Ys, Xs, seed=1234)
     t0 = time.perf_counter()
     proj, zmap = orc.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
     if workload != "projection":
         lab = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
         orc.frame_cellinfo(lab)
-    dt = time.perf_counter() - t0
-    return dt
+    print("CPU_BASELINE_SECONDS %.6f" % (time.perf_counter() - t0))
+
+
+def cpu_baseline(sample_yx, Z, workload, nproc):
+    """Runs the sample in `nproc` child processes at once (started BEFORE this process touches the GPU) and returns the
+    list of per-process seconds: nproc = 1 is the single-core figure, nproc = host cores the embarrassingly parallel
+    "N frames on N processes" one (scipy.ndimage / skimage are single-threaded)."""
+    import subprocess
+    Ys, Xs = sample_yx
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(nproc)]
+    secs = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed")
+        secs.append(float([l for l in out.splitlines() if l.startswith("CPU_BASELINE_SECONDS")][0].split()[1]))
+    return secs
 
 
 def bench_movie(args, rank, local_rank, world, dist, torch):
@@ -136,6 +158,8 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
@@ -143,6 +167,8 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unet-leg", action="store_true", help="skip the secondary U-Net leg of the default run")
+    ap.add_argument("--unet-steps", type=int, default=5, help="timed steps of the secondary U-Net leg (2 warm-up steps)")
     ap.add_argument("--include-upload", action="store_true",
                     help="also time the host->device copy of every frame (pinned host buffers, copied by the worker that "
                          "then processes the frame, so uploads overlap other workers' kernels); NOT the headline value")
@@ -154,6 +180,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    Y, X, Z = args.size
+    C = 2
+
+    # CPU baseline first: its child processes are started before this process initialises the GPU
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload != "movie":
+        wl = "classical" if args.workload in ("auto", "unet") else args.workload
+        Ys, Xs = min(Y, 1408), min(X, 1408)
+        scale = (Y * X) / float(Ys * Xs)
+        host_cores = os.cpu_count() or 1
+        try:
+            host_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            pass
+        one = cpu_baseline((Ys, Xs), Z, wl, 1)[0]
+        nproc = max(1, min(host_cores, 16))
+        many = cpu_baseline((Ys, Xs), Z, wl, nproc) if nproc > 1 else [one]
+        cpu = {"value": 1.0 / (one * scale), "unit": "frames/s", "cores": 1, "kind": "port", "host_cores": host_cores,
+               "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle (%s path), %.1f s on one core, scaled "
+                         "by pixel count" % (Ys, Xs, Z, scale, wl, one),
+               "n_process": {"processes": nproc, "value": nproc / (max(many) * scale), "unit": "frames/s",
+                             "sample": "the same crop in %d processes at once (one frame each), slowest %.1f s" % (nproc, max(many))}}
+
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -169,30 +218,28 @@ def main():
     if args.workload == "movie":
         return bench_movie(args, rank, local_rank, world, dist, torch)
     lib = _lib.lib()
-    Y, X, Z = args.size
-    C = 2
     workload = args.workload
-    has_seg = hasattr(lib, "tip_watershed_segmentation_f64_dev")
     if workload == "auto":
-        workload = "classical" if has_seg else "projection"
+        workload = "classical"
 
     # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
     import threading
     st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
     st_flip = np.ascontiguousarray(st[:, :, :, ::-1])
-    nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else 1
     steps_lock = threading.Lock()
 
     class Worker(object):
         """One frame in flight: own thread, own HIP stream / workspace pool (tip_init per thread), own resident buffers."""
 
-        def __init__(self, wid):
+        def __init__(self, wid, workload):
             self.wid = wid
+            self.workload = workload
             self.todo = threading.Semaphore(0)
             self.done = threading.Semaphore(0)
             self.jobs = []
             self.report = {}
             self.error = None
+            self.unet_ms = []
             self.thread = threading.Thread(target=self.run, daemon=True)
             self.thread.start()
             self.wait()  # wait for setup
@@ -206,12 +253,20 @@ def main():
 
         def run_inner(self):
             _lib.init(local_rank)
-            self.pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(workload == "unet"))
+            self.pipe = FramePipeline(C, Z, Y, X, reference_channel=0, airyscan=False, use_torch=(self.workload == "unet"))
             self.predictor = None
-            if workload == "unet":
+            if self.workload == "unet":
                 from tissue_image_processing_amd.prediction_local import SegmentationPredictor
                 self.predictor = SegmentationPredictor(None, (2, X, Y), device=local_rank)  # random-init (none ship upstream)
             self.frames = [self.pipe.upload_stack(st), self.pipe.upload_stack(st_flip)]
+            if self.predictor is not None:
+                # random-init weights give an all-or-nothing class map; shift the head bias so that the thresholded map
+                # (pl.py:168) covers half of the first frame: the tail then floods a boundary image with real structure
+                self.pipe.project(self.frames[0])
+                self.pipe.sync()
+                pj = self.pipe._proj_t
+                padded, _ = self.predictor.prepare_image(torch.stack([pj[1].T, pj[0].T]))
+                self.predictor.model.calibrate_head(padded, 0.5)
             self.host = None
             if args.include_upload:   # pinned host copies of the two frames; the device buffers are re-filled every step
                 self.host = [torch.from_numpy(st).pin_memory(), torch.from_numpy(st_flip).pin_memory()]
@@ -220,6 +275,8 @@ def main():
                 self.todo.acquire()
                 job = self.jobs.pop(0)
                 if job is None:
+                    self.frames = self.pipe = self.predictor = None
+                    self.done.release()
                     return
                 kind, arg = job
                 if kind == "steps":      # arg: shared iterator of step indices (workers pull, so no thread idles early)
@@ -230,13 +287,20 @@ def main():
                             break
                         self.step(i)
                     self.pipe.sync()
+                    if self.workload == "unet":
+                        torch.cuda.synchronize()
                 elif kind == "prof":
                     if arg == "on":
                         _lib.prof_reset()
                         _lib.prof_enable(True)
+                        if self.predictor is not None:
+                            self.predictor.forward_ms = []
                     else:
                         _lib.prof_enable(False)
                         self.report = _lib.prof_report()
+                        if self.predictor is not None:
+                            self.unet_ms = list(self.predictor.forward_ms or [])
+                            self.predictor.forward_ms = None
                 self.done.release()
 
         def step(self, i):
@@ -246,10 +310,10 @@ def main():
                 _lib.check(lib.tip_memcpy_h2d(_lib.dptr(self.frames[i % 2].ptr), ctypes.c_void_p(h.data_ptr()),
                                               ctypes.c_size_t(h.numel() * 2)))
             pipe.project(self.frames[i % 2])
-            if workload == "classical":
+            if self.workload == "classical":
                 pipe.segment(0)
                 pipe.cell_tables()
-            elif workload == "unet":
+            elif self.workload == "unet":
                 lab, _ = pipe.segment_unet(self.predictor)
                 pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
 
@@ -262,123 +326,175 @@ def main():
             if self.error is not None:
                 raise RuntimeError("bench worker %d failed: %r" % (self.wid, self.error))
 
-    workers = [Worker(w) for w in range(nthreads)]
-    del st, st_flip
-
-    def run_steps(n):
-        it = iter(range(n))
-        for w in workers:
-            w.submit(("steps", it))
-        for w in workers:
-            w.wait()
-
-    def all_workers(job):
-        for w in workers:
-            w.submit(job)
-        for w in workers:
-            w.wait()
-
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(max(args.warmup, nthreads))
-    barrier()
-    all_workers(("prof", "on"))
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    all_workers(("prof", "off"))
-    timed_reports = [dict(w.report) for w in workers]
-    # isolated pass for the roofline: ONE frame in flight, so that a kernel's duration is its own (with several frames in
-    # flight kernels of different frames share the chip and every per-kernel duration is inflated)
-    iso_steps = min(args.steps, 5)
-    workers[0].submit(("prof", "on")); workers[0].wait()
-    workers[0].submit(("steps", iter(range(iso_steps)))); workers[0].wait()
-    workers[0].submit(("prof", "off")); workers[0].wait()
-    iso_report = dict(workers[0].report)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_leg(workload, nthreads, steps, warmup):
+        """warmup untimed steps, then exactly `steps` timed steps between barriers; then an isolated pass (ONE frame in
+        flight) whose per-kernel HIP-event durations feed the roofline."""
+        workers = [Worker(w, workload) for w in range(nthreads)]
+
+        def run_steps(n, ws=workers):
+            it = iter(range(n))
+            for w in ws:
+                w.submit(("steps", it))
+            for w in ws:
+                w.wait()
+
+        def all_workers(job):
+            for w in workers:
+                w.submit(job)
+            for w in workers:
+                w.wait()
+
+        run_steps(max(warmup, nthreads))
+        barrier()
+        all_workers(("prof", "on"))
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        all_workers(("prof", "off"))
+        timed_reports = [dict(w.report) for w in workers]
+        unet_ms = [m for w in workers for m in w.unet_ms]
+        # isolated pass: with several frames in flight kernels of different frames share the chip and every per-kernel
+        # duration is inflated
+        iso_steps = min(steps, 5)
+        workers[0].submit(("prof", "on")); workers[0].wait()
+        run_steps(iso_steps, workers[:1])
+        workers[0].submit(("prof", "off")); workers[0].wait()
+        iso_report = dict(workers[0].report)
+        iso_unet_ms = list(workers[0].unet_ms)
+        all_workers(None)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return dict(elapsed=elapsed, timed=timed_reports, iso=iso_report, iso_steps=iso_steps, unet_ms=unet_ms,
+                    iso_unet_ms=iso_unet_ms, nthreads=nthreads, steps=steps, warmup=warmup)
+
+    def merge(reports):
+        rep = {}
+        for r in reports:
+            for k, (cnt_k, ms_k) in r.items():
+                c0, m0 = rep.get(k, (0, 0.0))
+                rep[k] = (c0 + cnt_k, m0 + ms_k)
+        return rep
+
+    def roofline_of(rep, nframes):
+        """The dominant kernel = the one with the largest time PER FRAME (all its launches of a frame added up).  Its
+        algorithmic bytes are per-frame figures, so achieved = bytes per frame / its time per frame -- for a
+        kernel launched once per frame that is bytes / launch duration; for the watershed's tile kernel (launched ~20 times
+        per frame over the same 50 MB job) it is NOT bytes / one launch."""
+        total_kernel_ms = sum(v[1] for v in rep.values())
+        name, (cnt, ms) = max(rep.items(), key=lambda kv: kv[1][1])
+        per_frame_s = ms / nframes / 1e3
+        launches_per_frame = cnt / float(nframes)
+        ab = algorithmic_bytes(name, C, Z, Y, X)
+        tr = pmc_traffic(name)
+        roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": tr * launches_per_frame if tr else None, "traffic_per_launch": tr,
+                "avg_launch_ms": ms / cnt, "launches_per_frame": launches_per_frame, "ms_per_frame": ms / nframes,
+                "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
+        if ab:
+            roof["achieved"] = ab / per_frame_s / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["algorithmic_bytes"] = ab
+            if tr:
+                roof["traffic_ratio"] = tr * launches_per_frame / ab
+        ops = algorithmic_dp_ops(name, Z, Y, X)
+        if ops:
+            tf = ops / per_frame_s / 1e12
+            roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
+                                 "frac": tf / (FP64_VALU_PEAK_TF / 2)}
+        return roof
+
+    def kernel_table(rep, nsteps):
+        out_k = {}
+        for k, v in rep.items():
+            out_k[k] = {"n_per_step": round(v[0] / nsteps, 2), "ms_per_step": round(v[1] / nsteps, 4)}
+            kb = algorithmic_bytes(k, C, Z, Y, X)
+            if kb:
+                gbs = kb / (v[1] / nsteps / 1e3) / 1e9     # per-frame bytes / per-frame time of this kernel
+                out_k[k]["hbm_GBps"] = round(gbs, 1)
+                out_k[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        return out_k
+
+    def unet_summary(leg):
+        """MFMA roofline of the U-Net forward pass: dense 3x3-conv flops of pl.py:31-72 at the padded size / the forward
+        pass's duration (torch CUDA events on torch's stream around the network only)."""
+        from tissue_image_processing_amd.prediction_local import _UNet, find_desired_shape
+        hp, wp = find_desired_shape(X, Y)
+        flops = _UNet.flops(None, hp, wp)
+        ms = leg["iso_unet_ms"] or leg["unet_ms"]
+        fwd_ms = float(np.median(ms)) if ms else None
+        dt = os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")
+        peak = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}[dt]
+        r = {"bound": "mfma", "dtype": dt, "flops_per_frame": flops, "peak": peak, "unit": "TFLOP/s",
+             "forward_ms": fwd_ms, "achieved": None, "frac": None,
+             "measured": "torch CUDA events around the network's forward pass (MIOpen convolutions), median of %d" % len(ms)}
+        if fwd_ms:
+            r["achieved"] = flops / (fwd_ms / 1e3) / 1e12
+            r["frac"] = r["achieved"] / peak
+        return r
+
+    wl_names = {
+        "projection": "surface_projection",
+        "classical": "surface_projection+watershed_segmentation+cell_tables",
+        "unet": "surface_projection+unet_segmentation(%s,random-init,head bias calibrated to 50%% foreground)+threshold/closing/watershed tail+cell_tables"
+                % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}
+
+    nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else 1
+    leg = run_leg(workload, nthreads, args.steps, args.warmup)
+    unet_leg = None
+    if workload == "classical" and not args.no_unet_leg and not args.include_upload:
+        unet_leg = run_leg("unet", 1, max(1, args.unet_steps), 2)
+    del st, st_flip
 
     if rank == 0:
-        def merge(reports):
-            rep = {}
-            for r in reports:
-                for k, (cnt_k, ms_k) in r.items():
-                    c0, m0 = rep.get(k, (0, 0.0))
-                    rep[k] = (c0 + cnt_k, m0 + ms_k)
-            return rep
-
-        def roofline_of(rep):
-            total_kernel_ms = sum(v[1] for v in rep.values())
-            name, (cnt, ms) = max(rep.items(), key=lambda kv: kv[1][1])
-            avg_s = ms / cnt / 1e3
-            ab = algorithmic_bytes(name, C, Z, Y, X)
-            roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": pmc_traffic(name), "avg_launch_ms": ms / cnt, "launches": cnt,
-                    "share_of_kernel_time": ms / total_kernel_ms if total_kernel_ms else None}
-            if ab:
-                roof["achieved"] = ab / avg_s / 1e9
-                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-                roof["algorithmic_bytes"] = ab
-            ops = algorithmic_dp_ops(name, Z, Y, X)
-            if ops:
-                tf = ops / avg_s / 1e12
-                roof["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF / 2, "unit": "Tinstr-lanes/s",
-                                     "frac": tf / (FP64_VALU_PEAK_TF / 2)}
-            return roof
-
-        def kernel_table(rep, nsteps):
-            out_k = {}
-            for k, v in rep.items():
-                out_k[k] = {"n_per_step": round(v[0] / nsteps, 2), "ms_per_step": round(v[1] / nsteps, 4)}
-                kb = algorithmic_bytes(k, C, Z, Y, X)
-                if kb:
-                    gbs = kb / (v[1] / v[0] / 1e3) / 1e9
-                    out_k[k]["hbm_GBps"] = round(gbs, 1)
-                    out_k[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
-            return out_k
-
-        roof = roofline_of(iso_report)
+        elapsed = leg["elapsed"]
+        roof = roofline_of(leg["iso"], leg["iso_steps"])
         roof["measured"] = ("HIP events on the library stream, isolated pass of %d steps with ONE frame in flight run right "
-                            "after the timed region (kernels of concurrent frames share the chip in the timed region)" % iso_steps)
-        timed = merge(timed_reports)
-        roof_timed = roofline_of(timed)
-        kernels = kernel_table(iso_report, iso_steps)
+                            "after the timed region (kernels of concurrent frames share the chip in the timed region)"
+                            % leg["iso_steps"])
+        roof_timed = roofline_of(merge(leg["timed"]), args.steps)
+        kernels = kernel_table(leg["iso"], leg["iso_steps"])
         # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are FP32-VALU bound, not HBM bound: 120 tap pairs x
         # (add + fma) + 1 multiply per output = 361 flop per voxel and pass; peak = MI355X FP32 vector (packed FMA) rate
         valu = {}
         for kname in ("score_fast_y", "score_fast_x"):
-            if kname in iso_report and iso_report[kname][0]:
-                cnt_k, ms_k = iso_report[kname]
+            if kname in leg["iso"] and leg["iso"][kname][0]:
+                cnt_k, ms_k = leg["iso"][kname]
                 tf = Z * Y * X * 361.0 / (ms_k / cnt_k / 1e3) / 1e12
                 valu[kname] = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                                "frac": tf / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
         out = {
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if workload != "unet" else "f32",
             "data": "synthetic",
-            "config": {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, {
-                "projection": "surface_projection",
-                "classical": "surface_projection+watershed_segmentation+cell_tables",
-                "unet": "surface_projection+unet_segmentation(%s,random-init)+cell_tables" % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}[workload]),
-                "frames_per_step": world, "frames_in_flight_per_gpu": nthreads, "includes_h2d_upload": bool(args.include_upload),
-                "parallelism": "frame-sharded dp%d, no data-path collective" % world},
+            "config": {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, wl_names[workload]),
+                       "value_is": workload, "frames_per_step": world, "frames_in_flight_per_gpu": leg["nthreads"],
+                       "includes_h2d_upload": bool(args.include_upload),
+                       "parallelism": "frame-sharded dp%d, no data-path collective" % world},
             "roofline": roof, "roofline_timed_region": roof_timed, "roofline_valu": valu, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            Ys, Xs = min(Y, 1408), min(X, 1408)
-            dt = cpu_baseline((Ys, Xs), Z, workload)
-            scale = (Y * X) / float(Ys * Xs)
-            out["cpu_baseline"] = {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle, %.1f s, "
-                                             "scaled by pixel count" % (Ys, Xs, Z, scale, dt)}
+        if workload == "unet":
+            out["roofline_unet"] = unet_summary(leg)
+        if unet_leg is not None:
+            ue = unet_leg["elapsed"]
+            out["unet"] = {
+                "workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, wl_names["unet"]),
+                "value": world * unet_leg["steps"] / ue, "unit": "frames/s", "steps": unet_leg["steps"],
+                "warmup": unet_leg["warmup"], "ms_per_step": 1e3 * ue / unet_leg["steps"], "dtype": "f32",
+                "frames_in_flight_per_gpu": 1, "roofline": unet_summary(unet_leg),
+                "kernels": kernel_table(unet_leg["iso"], unet_leg["iso_steps"]),
+                "note": "BASELINE config 3 as written; timed right after the classical leg in the same process"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -108,9 +108,15 @@ TIP_API int tip_label4_i32_dev(const int32_t *in, int32_t bg, int32_t *out, int 
 
 /* ---- watershed: skimage.segmentation.watershed(markers=None, connectivity=1) (bim.py:475, pl.py:194) */
 /* markers = label(local_minima(img)).  flags (out, may be NULL): bit0 = value ties between        */
-/* non-marker neighbours were met (FIFO order of the serial flood then not reproduced bit for bit). */
+/* non-marker neighbours were met; bit1 = the image is two-valued (pl.py:194) and was flooded by    */
+/* the generation-ranked mode, which reproduces the serial (value, age) heap order exactly, so bit0 */
+/* only means "not bit for bit" when bit1 is clear; bits 2.. = global-minimum fallback steps.      */
 TIP_API int tip_watershed_f64(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags);
 TIP_API int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host);
+/* Pop order of m equal-keyed heap entries pushed in raster order when popping entry i is followed  */
+/* by c[i] pushes of larger entries (skimage's heap_general.pxi mechanics; the marker phase of      */
+/* pl.py:194): e[i] = position of entry i in the pop order.  Host arrays, no device involved.      */
+TIP_API int tip_marker_pop_order_host(const uint8_t *c, long m, uint32_t *e);
 /* number of labels (= markers) produced by the calling thread's last watershed call                 */
 TIP_API int tip_last_watershed_labels(void);
 /* bim.py:446-476 as one device pipeline: local threshold -> Gaussian(sigma) -> watershed          */

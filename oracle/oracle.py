@@ -264,6 +264,16 @@ def watershed(img, markers=None, watershed_line=True):
     return lab
 
 
+def equal_key_pop_order(c):
+    """Order in which skimage's heap pops M equal-keyed markers when marker i pushes c[i] larger entries as it pops
+    (the marker phase of watershed() on a two-valued image, pl.py:194): order[t] = raster rank of the t-th popped marker."""
+    c = np.ascontiguousarray(c, dtype=np.uint8)
+    order = np.empty(c.size, np.int32)
+    rc = lib().orc_equal_key_pop_order(_p(c), ctypes.c_long(c.size), _p(order))
+    assert rc == 0
+    return order
+
+
 def watershed_segmentation(image, imgthresh, stdeviation, blocksize):
     """bim.py:446-476 (the 4-argument definition that shadows bim.py:417-443)."""
     seg = np.copy(image)

@@ -461,6 +461,41 @@ ORC_API int orc_watershed_f64(const double *img, int32_t *labels, long ny, long 
 }
 
 /* ------------------------------------------------------------------------- */
+/* Pop order of M equal-keyed marker entries (key (v, age 0), pushed in raster  */
+/* order) when popping marker i is followed by c[i] pushes of larger, unique    */
+/* entries -- the marker phase of the flood above on a two-valued image         */
+/* (pl.py:194), replayed on the same literal heap.  order[t] = marker popped    */
+/* t-th.  Checks the closed-form evaluation in the product's                    */
+/* csrc/tip_heaporder.hip.                                                      */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_equal_key_pop_order(const uint8_t *c, long m, int32_t *order)
+{
+    heap_t hp;
+    hp.space = m > 1024 ? m : 1024;
+    hp.items = 0;
+    hp.d = (heapitem *)malloc(sizeof(heapitem) * (size_t)hp.space);
+    if (!hp.d) return -1;
+    heapitem e, ne;
+    int64_t age = 0;
+    long t = 0;
+    for (long i = 0; i < m; i++) {
+        e.value = 0.0; e.age = 0; e.index = (int32_t)i; e.source = (int32_t)i;
+        if (h_push(&hp, &e)) return -1;
+    }
+    while (hp.items > 0) {
+        h_pop(&hp, &e);
+        if (e.value != 0.0) break;               /* first non-marker entry: the marker phase is over */
+        order[t++] = e.index;
+        for (int k = 0; k < c[e.index]; k++) {
+            ne.value = 255.0; ne.age = ++age; ne.index = -1; ne.source = -1;
+            if (h_push(&hp, &ne)) return -1;
+        }
+    }
+    free(hp.d);
+    return t == m ? 0 : -2;
+}
+
+/* ------------------------------------------------------------------------- */
 /* regionprops reductions (ti.py:891): per label area, bbox (min_row,min_col,  */
 /* max_row+1,max_col+1), coordinate sums (centroid = sum/area), and the        */
 /* skimage.measure.perimeter(neighbourhood=4) code histogram                   */

@@ -18,7 +18,7 @@ _tls = threading.local()
 c_int, c_long, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
 c_i64 = ctypes.c_int64
 
-TIP_ERR_ARG, TIP_ERR_INDEX = -2, -4
+TIP_ERR_ARG, TIP_ERR_INDEX, TIP_ERR_OVERFLOW = -2, -4, -6
 
 
 class TissueHipError(RuntimeError):
@@ -34,9 +34,33 @@ def load():
                 raise TissueHipError(
                     "libtissue_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                     "or `python -m tissue_image_processing_amd.build`. There is no CPU fallback." % LIB_PATH)
+            _preload_torch_hip_runtime()
             _lib = ctypes.CDLL(LIB_PATH)
             _lib.tip_prof_report.restype = c_int
     return _lib
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so with the same soname as /opt/rocm's, so a process gets
+    whichever copy is loaded first.  When this library came first and torch was imported afterwards (the U-Net path),
+    torch saw no device.  If torch is installed its copy is therefore loaded first, without importing torch -- the same
+    state as in a process that imported torch before this package (bench.py, the drivers)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def device_for_thread():

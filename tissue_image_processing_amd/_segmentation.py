@@ -151,12 +151,19 @@ def regionprops_arrays(labels, intensity=None, n=None):
 def neighbor_pairs(labels, cap=None):
     """Unique (hi, lo) pairs: a pixel labelled lo > 0 whose zero-padded 5x5 maximum is hi (ti.py:1822-1835)."""
     labels = np.ascontiguousarray(labels, dtype=np.int32)
+    grow = cap is None   # default capacity: planar label maps have ~3 pairs per cell; noisy maps get a bigger table
     if cap is None:
         cap = max(1024, 16 * (int(labels.max()) + 1))
-    pairs = np.empty((cap, 2), np.int32)
-    n = ctypes.c_int64(0)
-    _lib.check(_lib.lib().tip_neighbor_pairs_i32(_lib.ptr(labels), labels.shape[0], labels.shape[1], _lib.ptr(pairs),
-                                                 ctypes.c_int64(cap), ctypes.byref(n)))
+    while True:
+        pairs = np.empty((cap, 2), np.int32)
+        n = ctypes.c_int64(0)
+        rc = _lib.lib().tip_neighbor_pairs_i32(_lib.ptr(labels), labels.shape[0], labels.shape[1], _lib.ptr(pairs),
+                                               ctypes.c_int64(cap), ctypes.byref(n))
+        if rc == _lib.TIP_ERR_OVERFLOW and grow and cap < 8 * labels.size:
+            cap *= 8
+            continue
+        _lib.check(rc)
+        break
     p = pairs[:n.value].astype(np.int64)
     if p.size:
         p = p[np.lexsort((p[:, 1], p[:, 0]))]

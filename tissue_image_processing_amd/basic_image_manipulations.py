@@ -33,22 +33,14 @@ def gaussian_taps(sigma, truncate=4.0):
 
 
 def put_channel_axis_first(image, axes):
-    """bim.py:199-231.  Transposes only when the C axis index is > 0; order is (C, [T], [Z], X, Y)."""
-    channel_axis = axes.find("C")
-    if channel_axis > 0:
-        time_axis = axes.find("T")
-        x_axis = axes.find("X")
-        y_axis = axes.find("Y")
-        z_axis = axes.find("Z")
-        desired_order = (x_axis, y_axis)
-        if z_axis >= 0:
-            desired_order = (z_axis,) + desired_order
-        if time_axis >= 0:
-            desired_order = (time_axis,) + desired_order
-        desired_order = (channel_axis,) + desired_order
-        return np.transpose(image, axes=desired_order), desired_order
-    else:
+    """bim.py:199-231: (array, order) with the channel axis moved to the front and the remaining axes in the
+    reference's canonical order C, [T], [Z], X, Y.  The reference only reorders when "C" is present and not already
+    first; otherwise the array comes back untouched with the identity order."""
+    where = {name: axes.find(name) for name in "CTZXY"}
+    if where["C"] <= 0:
         return image, tuple(np.arange(len(axes)))
+    order = tuple(where[name] for name in "CTZXY" if name in "CXY" or where[name] >= 0)
+    return np.transpose(image, axes=order), order
 
 
 def _normalize_sigma(std, ndim):

@@ -210,20 +210,23 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k)
     return k;
 }
 
-// insert the ordered pair key into the global hash set; true for the call that created the entry
-__device__ __forceinline__ bool np_insert(unsigned long long key, unsigned long long *__restrict__ table, unsigned long long tmask)
+// insert the ordered pair key into the global hash set: 1 for the call that created the entry, 0 if it was there,
+// 2 when every slot was probed without finding the key or a free slot (more distinct pairs than slots: the table has
+// >= 2 * cap of them, so the caller's capacity is exceeded anyway and the host reports TIP_ERR_OVERFLOW)
+__device__ __forceinline__ int np_insert(unsigned long long key, unsigned long long *__restrict__ table, unsigned long long tmask)
 {
     unsigned long long h = mix64(key) & tmask;
-    for (;;) {
+    for (unsigned long long probes = 0; probes <= tmask; ++probes) {
         const unsigned long long cur = table[h];
-        if (cur == key) return false;
+        if (cur == key) return 0;
         if (cur == 0ULL) {
             const unsigned long long old = atomicCAS(&table[h], 0ULL, key);
-            if (old == 0ULL) return true;
-            if (old == key) return false;
+            if (old == 0ULL) return 1;
+            if (old == key) return 0;
         }
         h = (h + 1) & tmask;
     }
+    return 2;
 }
 
 constexpr int NPSLOTS = 256, NPNEW = 512;
@@ -276,7 +279,9 @@ __global__ void __launch_bounds__(256) k_neighbor_pairs(const int32_t *__restric
             }
             if (++probes == NPSLOTS) break;   // set full: treat as new, the global table dedupes
         }
-        if (fresh && np_insert(key, table, tmask)) {
+        const int ins = fresh ? np_insert(key, table, tmask) : 0;
+        if (ins == 2) atomicAdd(count, (unsigned long long)cap + 1ULL);   // table full: make the host see the overflow
+        if (ins == 1) {
             // this thread created the global entry: queue the pair; the block reserves list slots with ONE atomic
             // (a global counter bumped once per pair serialises: 25k same-address atomics cost 0.2 ms)
             const int q = atomicAdd(&s_nnew, 1);

@@ -15,10 +15,9 @@
 // keeps the result identical to the serial flood for any image whose non-marker pixels carry distinct values.
 // Equal values between non-marker neighbours are ordered by raster index instead of the serial heap's push age:
 // `flags` bit0 reports that such ties were met.
-// Mode B handles two-valued images (pl.py:194 floods a {0,255} boundary image): generation-synchronous BFS from the
-// low-valued components, ties inside a generation broken by raster index.  The serial result there depends on the
-// sift order of millions of equal-keyed heap entries; mode B is the same flood with a different, documented,
-// tie-break (label IoU vs the reference is reported by the tests).
+// Mode B handles two-valued images (pl.py:194 floods a {0,255} boundary image) EXACTLY: the pop order of the equal-keyed
+// markers follows from the array heap's mechanics (tip_heaporder.hip), everything after it is a FIFO, i.e. a
+// breadth-first search in generations whose pixels carry dense ranks (see the mode B section below).
 #include "tip_internal.h"
 #include "tip_uf.h"
 #include <cstdlib>
@@ -26,6 +25,7 @@
 namespace tip {
 
 int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
+int marker_pop_order(const uint8_t *c, long M, uint32_t *E);   // tip_heaporder.hip
 
 // ---- helpers ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long enc_f64(double d)
@@ -459,11 +459,15 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             __syncthreads();
         }
         cur ^= 1;
-        if (s_any) { certs = false; continue; }
+        // every wave reads the round's flags before thread 0 may reset them at the top of the next round (blocks of
+        // more than one wave: without the barrier the waves could take different branches here)
+        const int any = s_any, chg = s_chg;
+        if (WS_THREADS > 64) __syncthreads();
+        if (any) { certs = false; continue; }
         if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
         // local stall.  Pocket certificates cost ~40 plain rounds, and a tile that has just moved is re-run next launch
         // anyway (with its neighbours' news): only a tile that got nowhere at all tries them.
-        if (s_chg > 0) break;
+        if (chg > 0) break;
         certs = true;
     }
     __syncthreads();
@@ -742,73 +746,139 @@ __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v
     if (lane == 0 && committed == max_steps) atomicAdd(&info->unfinished, 1);   // (may have been finished exactly: harmless)
 }
 
-// ---- mode B: generation-synchronous BFS on a two-valued image --------------------------------------------------------
-// st: low = label / 0 / LINE, high = generation (0 for markers).  tent: tentative label of this generation's frontier
-// (0 none, >0 label), fate: 0 pending, 1 labelled, 2 line.
-__global__ void __launch_bounds__(256) k_bfs_prepare(unsigned long long *__restrict__ st, long n)
+// ---- mode B: two-valued image (pl.py:194 floods a {0, 255} boundary image) --------------------------------------------
+// Every low-valued pixel is a marker with the same heap key, and every other pixel has the same value, so the serial
+// flood is (a) the markers popping in the order the array heap's mechanics give equal keys -- tip_heaporder.hip -- and
+// (b) a FIFO: entries of the single remaining level pop in push order.  Push order = (pop rank of the pusher, neighbour
+// slot up / left / right / down), so the flood is a breadth-first search in generations whose pixels carry a dense RANK:
+// generation g+1's ranks come from sorting (rank of the gen-g pusher) * 4 + slot, done with a flag scatter + scan over
+// the 4 n_g possible keys.  When a pixel pops it becomes a line iff the neighbours labelled before it (earlier
+// generations, or the same generation with a smaller rank) carry two different labels, else it takes its pusher's label.
+//   st[p]   low 32: label / 0 undecided / LINE;  high 32: rank + 1 of a marker or of a candidate (0: not reached yet)
+//   cand[p] min over pushes of (key << 32 | pusher's label); ~0: never pushed
+constexpr unsigned long long MB_NONE = ~0ULL;
+
+__global__ void __launch_bounds__(256) k_mb_marker_flags(const unsigned long long *__restrict__ st, int *__restrict__ isroot, long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && st_lab(st[i]) > 0) st[i] = pack_st(st_lab(st[i]), 0);  // markers are generation 0
+    if (i < n) isroot[i] = st_lab(st[i]) > 0 ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_bfs_tent(unsigned long long *__restrict__ st, int *__restrict__ tent,
-                                                  unsigned char *__restrict__ fate, int Y, int X, int gen, WsInfo *info)
+// c[raster rank of the marker pixel] = number of its 4-neighbours inside the image that are not markers
+__global__ void __launch_bounds__(256) k_mb_push_counts(const unsigned long long *__restrict__ st, const int *__restrict__ mrank,
+                                                        unsigned char *__restrict__ c, int Y, int X)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= X) return;
     const int i = y * X + x;
-    tent[i] = 0;
-    if (st_lab(st[i]) != 0) return;
-    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
-    int s = 0;
-    bool conflict = false;
-    for (int k = 0; k < 4; ++k) {
-        if (nb[k] < 0) continue;
-        const unsigned long long q = st[nb[k]];
-        const int l = st_lab(q);
-        if (l > 0 && st_tref(q) < gen) {
-            if (s == 0) s = l;
-            else if (s != l) conflict = true;
-        }
-    }
-    if (s == 0) return;
-    if (conflict) { tent[i] = -1; fate[i] = 2; }
-    else { tent[i] = s; fate[i] = 0; atomicAdd(&info->undecided, 1); }
-    atomicAdd(&info->changed, 1);
+    if (st_lab(st[i]) <= 0) return;
+    int k = 0;
+    if (y > 0 && st_lab(st[i - X]) == 0) ++k;
+    if (x > 0 && st_lab(st[i - 1]) == 0) ++k;
+    if (x < X - 1 && st_lab(st[i + 1]) == 0) ++k;
+    if (y < Y - 1 && st_lab(st[i + X]) == 0) ++k;
+    c[mrank[i]] = (unsigned char)k;
 }
 
-__global__ void __launch_bounds__(256) k_bfs_resolve(const int *__restrict__ tent, unsigned char *__restrict__ fate, int Y, int X,
-                                                     WsInfo *info)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= X) return;
-    const int i = y * X + x;
-    const int t = tent[i];
-    if (t <= 0 || fate[i] != 0) return;
-    bool pending = false, line = false;
-    const int nb[2] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1};  // earlier raster index pops first
-    for (int k = 0; k < 2; ++k) {
-        if (nb[k] < 0) continue;
-        const int tq = tent[nb[k]];
-        if (tq > 0 && tq != t) {
-            const unsigned char f = fate[nb[k]];
-            if (f == 0) pending = true;
-            else if (f == 1) line = true;
-        }
-    }
-    if (line) { fate[i] = 2; atomicAdd(&info->changed, 1); }
-    else if (!pending) { fate[i] = 1; atomicAdd(&info->changed, 1); }
-    else atomicAdd(&info->undecided, 1);
-}
-
-__global__ void __launch_bounds__(256) k_bfs_commit(unsigned long long *__restrict__ st, const int *__restrict__ tent,
-                                                    const unsigned char *__restrict__ fate, long n, int gen)
+__global__ void __launch_bounds__(256) k_mb_init(unsigned long long *__restrict__ st, const int *__restrict__ mrank,
+                                                 const unsigned *__restrict__ E, unsigned long long *__restrict__ cand, long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int t = tent[i];
-    if (t == 0) return;
-    st[i] = (t > 0 && fate[i] == 1) ? pack_st(t, gen) : pack_st(LINE_LAB, gen);
+    const int l = st_lab(st[i]);
+    st[i] = l > 0 ? pack_st(l, (int)(E[mrank[i]] + 1u)) : 0ULL;
+    cand[i] = MB_NONE;
+}
+
+// a labelled pixel p of rank r pushes its undecided neighbours: key = r * 4 + slot, slot = position of the neighbour in
+// skimage's push order (up, left, right, down).  The first push of a pixel appends it to the next generation's list.
+__device__ __forceinline__ void mb_push_from(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
+                                             int *__restrict__ next, int *__restrict__ counter, int p, int Y, int X)
+{
+    const unsigned long long s = st[p];
+    const int l = st_lab(s);
+    if (l <= 0) return;
+    const unsigned long long r4 = (unsigned long long)(unsigned)(st_tref(s) - 1) * 4ULL;
+    const int y = p / X, x = p - y * X;
+    const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = nb[k];
+        if (u < 0 || st[u] != 0ULL) continue;
+        const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
+        if (atomicMin(&cand[u], val) == MB_NONE) next[atomicAdd(counter, 1)] = u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mb_push_markers(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
+                                                         int *__restrict__ next, int *__restrict__ counter, int Y, int X)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < X) mb_push_from(st, cand, next, counter, y * X + x, Y, X);
+}
+
+__global__ void __launch_bounds__(256) k_mb_push_list(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
+                                                      const int *__restrict__ list, int nlist, int *__restrict__ next,
+                                                      int *__restrict__ counter, int Y, int X)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nlist) mb_push_from(st, cand, next, counter, list[i], Y, X);
+}
+
+__global__ void __launch_bounds__(256) k_mb_flag_keys(const unsigned long long *__restrict__ cand, const int *__restrict__ next,
+                                                      int nnext, int *__restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnext) flag[(unsigned)(cand[next[i]] >> 32)] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_mb_assign_ranks(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                         const int *__restrict__ next, int nnext, const int *__restrict__ drank,
+                                                         int *__restrict__ list)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnext) return;
+    const int u = next[i];
+    const int r = drank[(unsigned)(cand[u] >> 32)];
+    st[u] = pack_st(0, r + 1);
+    list[r] = u;
+}
+
+// fate of the generation's pixels, in rank order: a pixel waits while a same-generation neighbour of smaller rank is
+// still pending (its fate decides whether this pixel sees a second label)
+__global__ void __launch_bounds__(256) k_mb_resolve(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                    const int *__restrict__ list, int nlist, int Y, int X, WsInfo *info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlist) return;
+    const int p = list[i];
+    volatile unsigned long long *vst = st;
+    if (st_lab(vst[p]) != 0) return;
+    const int myr = i + 1;
+    const int y = p / X, x = p - y * X;
+    const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        int l0 = 0;
+        bool diff = false, pending = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (nb[k] < 0) continue;
+            const unsigned long long s = vst[nb[k]];
+            const int l = st_lab(s);
+            if (l > 0) {
+                if (l0 == 0) l0 = l;
+                else if (l != l0) diff = true;
+            } else if (l == 0) {
+                const int r = st_tref(s);
+                pending |= r != 0 && r < myr;
+            }
+        }
+        if (!pending) {
+            vst[p] = pack_st(diff ? LINE_LAB : (int)(unsigned)(cand[p] & 0xffffffffULL), myr);
+            return;
+        }
+    }
+    atomicAdd(&info->undecided, 1);   // (rare: only pixels behind a chain of same-generation neighbours get here)
 }
 
 __global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__restrict__ st, int32_t *__restrict__ out, long n)
@@ -870,28 +940,67 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     const bool two_valued = h.n_other == 0 && h.emin != h.emax;
     if (h.n_markers > 0 && two_valued) {
         flags |= 2;  // mode B
-        int *tent = parent;                       // reuse
-        unsigned char *fate = (unsigned char *)flag;
-        TIP_LAUNCH("bfs_prepare", k_bfs_prepare, dim3(cdiv(n, 256)), dim3(256), 0, st, n);
-        for (int gen = 1;; ++gen) {
-            TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-            TIP_LAUNCH("bfs_tent", k_bfs_tent, dim3(cdiv(X, 256), Y), dim3(256), 0, st, tent, fate, Y, X, gen, info);
-            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+        // (a) pop order of the equal-keyed markers: per-marker push counts -> host recurrence (tip_heaporder.hip) -> ranks
+        int *mrank = rank, *total_d = &info->n_markers;    // (n_markers was copied out above; reused as the scan's total)
+        TIP_LAUNCH("mb_marker_flags", k_mb_marker_flags, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st, isroot, n);
+        if ((rc = exclusive_scan_i32(isroot, mrank, n, total_d))) return rc;
+        int M = 0;
+        TIP_HIP(hipMemcpyAsync(&M, total_d, sizeof(int), hipMemcpyDeviceToHost, s));
+        TIP_HIP(hipStreamSynchronize(s));
+        unsigned char *c_d = ws.get<unsigned char>((size_t)M);
+        unsigned *E_d = ws.get<unsigned>((size_t)M);
+        unsigned long long *cand = ws.get<unsigned long long>(n);
+        int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1);
+        int *kflag = ws.get<int>((size_t)4 * M + 4), *drank = ws.get<int>((size_t)4 * M + 4);
+        if (!c_d || !E_d || !cand || !lists || !counter || !kflag || !drank) return TIP_ERR_NOMEM;
+        TIP_LAUNCH("mb_push_counts", k_mb_push_counts, dim3(cdiv(X, 256), Y), dim3(256), 0, (const unsigned long long *)st,
+                   (const int *)mrank, c_d, Y, X);
+        {
+            std::vector<unsigned char> hc((size_t)M);
+            std::vector<uint32_t> hE((size_t)M);
+            TIP_HIP(hipMemcpyAsync(hc.data(), c_d, (size_t)M, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
-            for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
-            if (h.changed == 0) break;
-            int pending = h.undecided;
-            while (pending > 0) {
+            if ((rc = marker_pop_order(hc.data(), M, hE.data()))) return rc;
+            TIP_HIP(hipMemcpyAsync(E_d, hE.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
+            TIP_HIP(hipStreamSynchronize(s));   // hE goes out of scope
+        }
+        TIP_LAUNCH("mb_init", k_mb_init, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)mrank, (const unsigned *)E_d, cand, n);
+        // (b) generations
+        int *cur_list = lists, *next_list = lists + n;     // next_list doubles as the unordered append buffer: the ranked
+        int *unordered = parent;                            // list is written from a separate buffer (parent is free here)
+        long keyspace = 4L * M;
+        int ncur = 0;
+        for (int gen = 0;; ++gen) {
+            TIP_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+            if (gen == 0)
+                TIP_LAUNCH("mb_push_markers", k_mb_push_markers, dim3(cdiv(X, 256), Y), dim3(256), 0, st, cand, unordered, counter, Y, X);
+            else
+                TIP_LAUNCH("mb_push_list", k_mb_push_list, dim3(cdiv(ncur, 256)), dim3(256), 0, st, cand, (const int *)cur_list, ncur,
+                           unordered, counter, Y, X);
+            int nnext = 0;
+            TIP_HIP(hipMemcpyAsync(&nnext, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+            TIP_HIP(hipStreamSynchronize(s));
+            if (nnext == 0) break;
+            TIP_HIP(hipMemsetAsync(kflag, 0, (size_t)keyspace * sizeof(int), s));
+            TIP_LAUNCH("mb_flag_keys", k_mb_flag_keys, dim3(cdiv(nnext, 256)), dim3(256), 0, (const unsigned long long *)cand,
+                       (const int *)unordered, nnext, kflag);
+            if ((rc = exclusive_scan_i32(kflag, drank, keyspace, nullptr))) return rc;
+            TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
+                       (const int *)unordered, nnext, (const int *)drank, next_list);
+            for (int pass = 0, waiting = nnext + 1;; ++pass) {
                 TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-                TIP_LAUNCH("bfs_resolve", k_bfs_resolve, dim3(cdiv(X, 256), Y), dim3(256), 0, (const int *)tent, fate, Y, X, info);
+                TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
+                           (const int *)next_list, nnext, Y, X, info);
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
-                for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
-                if (h.changed == 0 && h.undecided > 0) return fail(TIP_ERR_HIP, "watershed: BFS resolve made no progress");
-                pending = h.undecided;
+                if (h.undecided == 0) break;
+                // the smallest-ranked waiting pixel has no pending neighbour of smaller rank, so every pass decides some
+                if (h.undecided >= waiting) return fail(TIP_ERR_HIP, "watershed: generation %d made no progress", gen);
+                waiting = h.undecided;
             }
-            TIP_LAUNCH("bfs_commit", k_bfs_commit, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)tent,
-                       (const unsigned char *)fate, n, gen);
+            std::swap(cur_list, next_list);
+            ncur = nnext;
+            keyspace = 4L * nnext;
         }
     } else if (h.n_markers > 0) {
         const int tilesX = cdiv(X, WT_FAST), tilesY = cdiv(Y, WT_FAST), ntiles = tilesX * tilesY;
@@ -909,7 +1018,11 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         int burst_no = 0;
         bool early_done = false;
         int post_end_burst = -1;   // index of the first burst after the early endgame
+        // test hooks, read once: TIP_WS_DEBUG prints per-burst counters, TIP_WS_NO_ENDGAME / TIP_WS_NO_WIDE exercise the
+        // fallback machinery
         const int dbg = getenv("TIP_WS_DEBUG") ? 1 : 0;
+        const bool no_endgame = getenv("TIP_WS_NO_ENDGAME") != nullptr, no_wide = getenv("TIP_WS_NO_WIDE") != nullptr;
+        int *cursor = nullptr, *cellsbuf = nullptr, *slot = nullptr, *roots = nullptr, *ncomp_d = nullptr;   // endgame workspaces
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
             // tile launches go out in bursts with ONE host check per burst (a launch whose tiles are all inactive costs
@@ -933,7 +1046,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
-            if (getenv("TIP_WS_DEBUG"))
+            if (dbg)
                 fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d\n", iter, wide ? "wide" : "fast",
                         h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed);
             // The first two bursts do the bulk; what is left then are a few thousand pixels in long dependency chains
@@ -941,7 +1054,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // right away instead of waiting for the tile rounds to stall.
             // (measured on 2048^2 frames: after 10 launches with 32 serial steps per component 2.9 ms per frame; after 6
             // launches 4.0 ms, after 12 3.05 ms, 512 steps 3.7 ms, no early endgame 3.6 ms)
-            const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !getenv("TIP_WS_NO_ENDGAME");
+            const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !no_endgame;
             if (h.changed > 0 && !early_endgame) { wide = false; continue; }
             const bool quiescent = h.changed == 0;
             long und_total = 1, front_total = 1;
@@ -959,7 +1072,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // quiescent and no undecided pixel touches a labelled one: what is left is enclosed by lines and stays 0.
             // (After a wide pass the fine tiles' counts are stale, so this shortcut only applies to the fine rounds.)
             if (front_total == 0 && !wide && quiescent) break;
-            if (!wide_after_endgame && !getenv("TIP_WS_NO_ENDGAME")) {   // (env: test hook that exercises the fallback machinery)
+            if (!wide_after_endgame && !no_endgame) {
                 // serial rule on every connected component of undecided pixels that fits one wave's LDS copy
                 if (!early_done) post_end_burst = burst_no;
                 early_done = true;
@@ -969,8 +1082,10 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_LAUNCH("ws_end_count", k_end_count, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
                            (const int *)parent, flag, isroot, n);
                 int *off = rank;                                            // start of every component's cells in cellsbuf
-                int *cursor = ws.get<int>(n), *cellsbuf = ws.get<int>(n), *slot = ws.get<int>(n), *roots = ws.get<int>(n),
-                    *ncomp_d = ws.get<int>(2);                              // [0] components, [1] cells
+                if (!cursor) {   // taken from the pool once per call (lazily: many frames never get here twice)
+                    cursor = ws.get<int>(n); cellsbuf = ws.get<int>(n); slot = ws.get<int>(n); roots = ws.get<int>(n);
+                    ncomp_d = ws.get<int>(2);                               // [0] components, [1] cells
+                }
                 if (!cursor || !cellsbuf || !slot || !roots || !ncomp_d) return TIP_ERR_NOMEM;
                 TIP_HIP(hipMemsetAsync(ncomp_d, 0, 2 * sizeof(int), s));
                 TIP_LAUNCH("ws_end_offsets", k_end_offsets, dim3(cdiv(n, 256)), dim3(256), 0, (const int *)flag, (const int *)isroot,
@@ -988,7 +1103,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
                 for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
-                if (getenv("TIP_WS_DEBUG"))
+                if (dbg)
                     fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d, unfinished %d\n", ncomp, h.changed, h.undecided, h.unfinished);
                 endgames++;
                 if (h.undecided == 0 && h.unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
@@ -1003,7 +1118,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 wide = true;
                 continue;
             }
-            if (!wide && !getenv("TIP_WS_NO_WIDE")) { wide = true; continue; }  // no progress: one wide launch over every tile
+            if (!wide && !no_wide) { wide = true; continue; }  // no progress: one wide launch over every tile
             wide = false;
             // still nothing: pockets too large to certify locally -> commit the pixel with the globally smallest pop time
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);

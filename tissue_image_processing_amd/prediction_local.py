@@ -24,29 +24,27 @@ from . import _lib
 
 
 def find_desired_shape(shape_y, shape_x):
-    """pl.py:10-19: next power of two >= each extent."""
-    first_axis_pixels = second_axis_pixels = None
-    for i in range(shape_y):
-        if 2 ** i >= shape_y:
-            first_axis_pixels = 2 ** i
-            break
-    for j in range(shape_x):
-        if 2 ** j >= shape_x:
-            second_axis_pixels = 2 ** j
-            break
-    return first_axis_pixels, second_axis_pixels
+    """pl.py:10-19: the smallest power of two >= each extent (the network halves the frame three times)."""
+    if shape_y < 1 or shape_x < 1:
+        raise UnboundLocalError("find_desired_shape: extents must be >= 1")   # what the reference's empty loop ends in
+    return 1 << (int(shape_y) - 1).bit_length(), 1 << (int(shape_x) - 1).bit_length()
 
 
 def normalize_channel(image):
-    """pl.py:21-29 (host numpy; the device path in SegmentationPredictor does the same arithmetic with torch)."""
-    new_image = np.copy(image)
+    """pl.py:21-29: clip to the [1st, 99th] percentile and scale to [0, 1].
+
+    The reference writes the two percentiles INTO a copy of the input, so the clip values take the input's dtype: for
+    the uint16 planes the GUI hands over (gui.py:2059-2061) they are truncated to integers, for float32 they are rounded
+    to float32 (and numpy 1.x, the reference's environment, then keeps the arithmetic in float32); float64 is plain."""
+    image = np.asarray(image)
     per99 = np.percentile(image, 99)
     per1 = np.percentile(image, 1)
-    new_image[image > per99] = per99
-    new_image[image < per1] = per1
-    new_image = new_image - per1
-    new_image = new_image / (per99 - per1)
-    return new_image
+    kind = image.dtype
+    clipped = np.where(image > per99, np.asarray(per99).astype(kind), image)
+    clipped = np.where(image < per1, np.asarray(per1).astype(kind), clipped)
+    if kind == np.float32:
+        return (clipped - np.float32(per1)) / np.float32(per99 - per1)
+    return (clipped - per1) / (per99 - per1)
 
 
 _FILTERS = (128, 256, 512)
@@ -150,7 +148,21 @@ class _UNet(object):
             x = x * p[name + ".b" + k + ".s"] + p[name + ".b" + k + ".t"]
         return x
 
-    def forward(self, x):
+    def calibrate_head(self, x, fraction):
+        """Synthetic-weights helper (bench / tests; no trained weights ship with the reference): shifts the bias of the
+        1x1 head so that class 0 exceeds the tail's 0.1 threshold (pl.py:168) on `fraction` of the pixels of input `x`.
+        Random-init features follow the input's structure, so the thresholded map then has cell-sized blobs instead of
+        being all-or-nothing, and the post-network tail sees a realistic boundary image."""
+        torch = self.torch
+        z = self.forward(x, logits=True)
+        d = (z[0, 0] - z[0, 1]).reshape(-1).float()
+        k = min(max(int(round((1.0 - fraction) * d.numel())), 1), d.numel())
+        cut = float(torch.kthvalue(d, k).values)
+        shift = float(np.log(0.1 / 0.9)) - cut          # p0 > 0.1  <=>  z0 - z1 > ln(1/9)
+        self.p["head.b"][0] += shift
+        return shift
+
+    def forward(self, x, logits=False):
         """x: (1, C, H, W) tensor on the device -> class probabilities (1, 2, H, W) float32."""
         torch = self.torch
         F = torch.nn.functional
@@ -168,6 +180,8 @@ class _UNet(object):
                 x = torch.cat([x, skips[2 - i]], dim=1)
                 x = self._double(x, "u%d" % i)
             x = F.conv2d(x, self.p["head.w"], self.p["head.b"])
+            if logits:
+                return x.float()
             return torch.softmax(x.float(), dim=1)
 
     def flops(self, h, w):
@@ -218,6 +232,7 @@ class SegmentationPredictor:
         first_axis_shape, second_axis_shape = find_desired_shape(image_shape[-2], image_shape[-1])
         self.model_shape = (first_axis_shape, second_axis_shape, 2)
         self.model = self.initialize_model()
+        self.forward_ms = None   # bench.py sets this to a list: per-call duration of the network's forward pass
 
     def initialize_model(self):
         weights = load_keras_weight_list(self.weights_path)
@@ -229,11 +244,21 @@ class SegmentationPredictor:
         Returns a torch tensor laid out (1, C, X', Y') (the NCHW view of the reference's NHWC array) and npad."""
         torch = self.torch
         if isinstance(image, torch.Tensor):
-            t = image.to(device=self.device, dtype=torch.float64)
+            src_dtype = image.dtype
+            t = image.to(device=self.device)
         else:
-            t = torch.as_tensor(np.ascontiguousarray(image), device=self.device).to(torch.float64)
+            arr = np.ascontiguousarray(image)
+            if arr.dtype == np.uint16:          # torch has no arithmetic on uint16: the values fit int32
+                arr = arr.astype(np.int32)
+            elif arr.dtype in (np.uint32, np.uint64):
+                arr = arr.astype(np.int64)
+            t = torch.as_tensor(arr, device=self.device)
+            src_dtype = t.dtype
         if t.dim() != 3:
             raise ValueError("image should be in axes order (C, Y, X)")
+        integer_in = not src_dtype.is_floating_point
+        single_in = src_dtype == torch.float32
+        t = t.to(torch.float64)                 # exact for every integer / float32 input value
         C, Y, X = t.shape
         chans = []
         for c in range(C):
@@ -241,8 +266,19 @@ class SegmentationPredictor:
             srt = torch.sort(ch.reshape(-1)).values
             per99 = _percentile_linear_t(srt, 99)
             per1 = _percentile_linear_t(srt, 1)
-            ch = torch.clamp(ch, min=per1, max=per99)
-            chans.append((ch - per1) / (per99 - per1))
+            # normalize_channel (pl.py:21-29) stores the percentiles into a copy of the INPUT: the clip values take its dtype
+            hi, lo = per99, per1
+            if integer_in:
+                hi, lo = float(np.trunc(per99)), float(np.trunc(per1))
+            elif single_in:
+                hi, lo = float(np.float32(per99)), float(np.float32(per1))
+            clipped = torch.where(ch > per99, torch.full_like(ch, hi), ch)
+            clipped = torch.where(ch < per1, torch.full_like(ch, lo), clipped)
+            if single_in:                        # numpy 1.x keeps float32 array (op) float64 scalar in float32
+                n32 = (clipped.to(torch.float32) - float(np.float32(per1))) / float(np.float32(per99 - per1))
+                chans.append(n32.to(torch.float64))
+            else:
+                chans.append((clipped - per1) / (per99 - per1))
         norm = torch.stack(chans)                      # (C, Y, X) float64
         xy = norm.permute(0, 2, 1)                     # np.transpose(normalized) -> (X, Y, C); NCHW view: (C, X, Y)
         shape1, shape2 = X, Y
@@ -258,7 +294,14 @@ class SegmentationPredictor:
     def predict(self, image, debug=False, return_device=False):
         torch = self.torch
         padded, npad = self.prepare_image(image)
+        if self.forward_ms is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         prob = self.model.forward(padded)                              # (1, 2, X', Y') float32
+        if self.forward_ms is not None:
+            ev1.record()
+            ev1.synchronize()
+            self.forward_ms.append(ev0.elapsed_time(ev1))
         unp = prob[:, :, npad[1][0]:, npad[2][0]:]
         p0 = unp[0, 0]
         labels, hc = self.segment_probability(p0, return_device=return_device)

@@ -47,40 +47,35 @@ def find_local_maxima(arr, window_size=7):
     return np.abs(blurred - maxima) < 1e-6
 
 
+def _type_bits(type):
+    return np.asarray(type).astype(np.uint8)
+
+
 def is_positive_for_type(type, type_index):
-    """ti.py:146-176 (scalar/array index branch; the tuple branch uses np.bool, removed from numpy)."""
+    """ti.py:146-176: is bit `type_index` of the cell-type byte set (INVALID_TYPE_INDEX never is)?  `type_index` may be a
+    pair (types that must be set, types that must be clear).  Arrays in, boolean arrays out; scalars give numpy bools."""
     if isinstance(type_index, tuple):
-        pos_types, neg_types = type_index
-        res = np.ones_like(np.asarray(type), dtype=bool)
-        for t in pos_types:
-            res &= np.asarray(is_positive_for_type(type, t), dtype=bool)
-        for t in neg_types:
-            res &= ~np.asarray(is_positive_for_type(type, t), dtype=bool)
-        return res
+        must_have, must_lack = type_index
+        verdict = np.ones(np.shape(type), dtype=bool)
+        for t in must_have:
+            verdict = verdict & np.asarray(is_positive_for_type(type, t), dtype=bool)
+        for t in must_lack:
+            verdict = verdict & ~np.asarray(is_positive_for_type(type, t), dtype=bool)
+        return verdict if verdict.ndim else bool(verdict)
     if type_index < 0:
         return False
-    binary_location = (1 << type_index)
-    type = np.array(type).astype(np.uint8)
-    binary_location = np.ones_like(type).astype(np.uint8) * binary_location
-    res = np.bitwise_and(type, binary_location) == binary_location
-    if hasattr(res, "__len__"):
-        res[type == INVALID_TYPE_INDEX] = False
-    return res
+    bits = _type_bits(type)
+    bit = np.uint8(1 << type_index)
+    return ((bits & bit) == bit) & (bits != INVALID_TYPE_INDEX)
 
 
 def change_type(current_type, type_index, is_positive):
-    """ti.py:179-191."""
-    binary_location = (1 << type_index)
-    res = np.array(current_type).astype(np.uint8)
-    if hasattr(res, "__len__") and res.ndim > 0:
-        res[np.asarray(current_type) == INVALID_TYPE_INDEX] = 0
-    elif res == INVALID_TYPE_INDEX:
-        res = np.array(0).astype(np.uint8)
-    binary_location = binary_location * np.ones_like(current_type).astype(np.uint8)
-    res = np.bitwise_and(res, np.bitwise_not(binary_location))
-    if is_positive:
-        res = np.bitwise_or(res, binary_location)
-    return res
+    """ti.py:179-191: the type byte with bit `type_index` set or cleared; an invalid cell (255) starts from 0."""
+    bits = _type_bits(current_type)
+    bits = np.where(bits == INVALID_TYPE_INDEX, np.uint8(0), bits)
+    bit = np.uint8(1 << type_index)
+    out = (bits | bit) if is_positive else (bits & np.uint8(~bit & 0xFF))
+    return out.astype(np.uint8)
 
 
 class TissueHipMixin(object):
@@ -96,29 +91,22 @@ class TissueHipMixin(object):
         number_of_cells = int(np.max(labels))
         if number_of_cells == 0:
             return 0
+        rp = seg.regionprops_arrays(labels, n=number_of_cells)      # SoA over labels 1..n, one device pass
+        present = rp["area"] > 0                                      # labels that do not occur keep the table's zeros
+        columns = {"label": rp["label"], "area": rp["area"], "perimeter": rp["perimeter"], "cx": rp["cx"], "cy": rp["cy"]}
+        for j, edge in enumerate(("min_row", "min_col", "max_row", "max_col")):
+            columns["bounding_box_" + edge] = rp["bbox"][:, j]
         cells_info = make_df(number_of_cells, CELL_INFO_SPECS)
-        rp = seg.regionprops_arrays(labels, n=number_of_cells)
-        present = rp["area"] > 0
-        idx = np.nonzero(present)[0]
-        cells_info["perimeter"] = cells_info["perimeter"].astype(np.float64)
-        cells_info["cx"] = cells_info["cx"].astype(np.float64)
-        cells_info["cy"] = cells_info["cy"].astype(np.float64)
-        cells_info.loc[idx, "label"] = rp["label"][idx]
-        cells_info.loc[idx, "area"] = rp["area"][idx]
-        cells_info.loc[idx, "perimeter"] = rp["perimeter"][idx]
-        cells_info.loc[idx, "cx"] = rp["cx"][idx]
-        cells_info.loc[idx, "cy"] = rp["cy"][idx]
-        cells_info.loc[idx, "bounding_box_min_row"] = rp["bbox"][idx, 0]
-        cells_info.loc[idx, "bounding_box_min_col"] = rp["bbox"][idx, 1]
-        cells_info.loc[idx, "bounding_box_max_row"] = rp["bbox"][idx, 2]
-        cells_info.loc[idx, "bounding_box_max_col"] = rp["bbox"][idx, 3]
-        areas = cells_info.area.to_numpy()
-        mean_area = np.mean(areas)
-        max_area = self.max_cell_area * mean_area
-        min_area = self.min_cell_area * mean_area
-        cells_info.loc[:, "valid"] = np.logical_and(areas < max_area, areas > min_area).astype(int)
+        for name, values in columns.items():
+            full = np.zeros(number_of_cells, dtype=np.float64 if name in ("perimeter", "cx", "cy") else np.int64)
+            full[present] = np.asarray(values)[present]
+            cells_info[name] = full
+        # ti.py:903-907: a cell is valid when its area lies strictly between min/max_cell_area times the mean area
+        areas = cells_info["area"].to_numpy()
+        smallest, largest = self.min_cell_area * areas.mean(), self.max_cell_area * areas.mean()
+        cells_info["valid"] = ((areas > smallest) & (areas < largest)).astype(int)
         self.set_cells_info(frame_number, cells_info)
-        self.find_neighbors(frame_number, only_for_labels=cells_info.query("valid == 1").index.to_numpy() + 1)
+        self.find_neighbors(frame_number, only_for_labels=np.flatnonzero(cells_info["valid"].to_numpy() == 1) + 1)
         return 0
 
     # ---- C2 -------------------------------------------------------------------------------------------------

@@ -360,6 +360,66 @@ def gold_unet_tail():
     save("unet_tail", p0=p0, closed=e, hc=hc, boundary=boundary, labels=ws)
 
 
+def gold_unet_predict():
+    """U1 + U3-U5 from the reference's own Segmentation/prediction_local.py: tensorflow (absent) and tifffile.imwrite
+    (debug dumps to hard-coded C:\\ paths) are stubbed, the class is created without __init__ (which would build the Keras
+    model) and given a fake model whose predict() returns a seeded probability map, so that find_desired_shape,
+    normalize_channel, prepare_image and the whole post-network tail of predict() (pl.py:124-199) run as written."""
+    _stub("tensorflow")
+    _stub("tifffile", imwrite=lambda *a, **k: None)
+    sys.path.insert(0, os.path.join(REF, "Segmentation"))
+    import prediction_local as pl  # reference
+    out = {}
+    shapes = np.array([[1, 1], [2, 3], [64, 65], [100, 70], [127, 129], [512, 513], [2048, 2048], [1000, 4097]])
+    out["fds_in"] = shapes
+    out["fds_out"] = np.array([pl.find_desired_shape(int(a), int(b)) for a, b in shapes])
+    rng = np.random.default_rng(91)
+    img = (rng.gamma(2.0, 300.0, (2, 100, 70))).astype(np.float64)      # (C, Y, X)
+    img[1] = np.round(img[1])                                             # ties around the percentiles
+    out["image"] = img
+    out["norm_c0"] = pl.normalize_channel(img[0])
+    out["norm_c1"] = pl.normalize_channel(img[1])
+    u16 = rng.integers(0, 60000, (2, 33, 47)).astype(np.uint16)           # what the GUI hands over: uint16 planes
+    out["image_u16"] = u16
+    out["norm_u16_c0"] = pl.normalize_channel(u16[0])
+
+    class FakeModel(object):
+        def __init__(self, prob):
+            self.prob = prob
+
+        def predict(self, x):
+            assert x.shape == self.prob.shape[:3] + (2,)
+            return self.prob
+
+    pred = object.__new__(pl.SegmentationPredictor)
+    pred.weights_path = None
+    pred.model_shape = (128, 128, 2)
+    pred.initialize_model = lambda: None
+    padded, npad = pred.prepare_image(img)
+    out["padded"] = padded
+    out["npad"] = np.array(npad)
+    p = ndi.gaussian_filter(rng.random((128, 128)), 3.0)
+    p = (p - p.min()) / (p.max() - p.min())
+    prob = np.stack([p, 1 - p], axis=-1)[None].astype(np.float32)         # (1, X', Y', 2)
+    pred.model = FakeModel(prob)
+    ws, hc = pred.predict(img)
+    out["prob"] = prob
+    out["labels"] = ws
+    out["hc"] = hc
+    # a second shape that needs a model_shape change inside prepare_image (pl.py:113-115)
+    img2 = rng.random((2, 40, 150)) * 4000
+    pred2 = object.__new__(pl.SegmentationPredictor)
+    pred2.weights_path = None
+    pred2.model_shape = (64, 64, 2)
+    pred2.initialize_model = lambda: None
+    padded2, npad2 = pred2.prepare_image(img2)
+    out["image2"] = img2
+    out["padded2"] = padded2
+    out["npad2"] = np.array(npad2)
+    out["model_shape2"] = np.array(pred2.model_shape)
+    save("unet_predict", **out)
+
+
 def gold_weights():
     """Gaussian tap weights exactly as this interpreter's scipy Python layer builds them (np.exp is not
     correctly rounded and differs between numpy builds, so the taps are part of the golden environment)."""
@@ -420,6 +480,7 @@ if __name__ == "__main__":
     gold_cellinfo(la, lb)
     gold_celltypes()
     gold_unet_tail()
+    gold_unet_predict()
     gold_tracking()
     gold_drift()
     print("done")
