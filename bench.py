@@ -125,16 +125,14 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
     sites_t, is_hc = synthetic.make_movie_sites(Y, X, T, seed=5)
     mine = list(range(rank, T, world))
     stacks = {t: synthetic.make_stack(Z, Y, X, seed=200 + t, sites=sites_t[t], is_hc=is_hc) for t in mine}
-    backend = movie.GpuFrameBackend(2, Z, Y, X, device=local_rank)
+    backend = movie.GpuFrameBackend(2, Z, Y, X, device=local_rank, keep_planes=True)
     backend.process_frame(-1, stacks[mine[0]])        # warm-up (allocations)
-    drifts = np.zeros((T, 2))
-    drifts[1:] = (0.5, -0.3)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, dist if world > 1 else None,
-                                    torch.device("cuda", local_rank) if world > 1 else "cpu", drifts)
+                                    torch.device("cuda", local_rank) if world > 1 else "cpu", estimate_drift=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -149,8 +147,10 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": T / elapsed, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d_c2_u16:movie(%d frames, host upload included)+track_stitching" % (Y, X, Z, T),
-                       "parallelism": "frame-sharded dp%d, RCCL gather of per-frame tables to rank 0" % world,
+            "config": {"workload": "%dx%dx%d_c2_u16:movie(%d frames, host upload included)+drift estimation+track_stitching" % (Y, X, Z, T),
+                       "parallelism": "frame-sharded dp%d, neighbour-rank plane exchange for the drift, RCCL gather of "
+                                      "per-frame tables to rank 0" % world,
+                       "mean_abs_drift": [float(v) for v in np.mean(np.abs([tb["drift"] for tb in tabs[1:]]), axis=0)],
                        "tracks": n_tracks, "cells_last_frame": int(ids[-1].size)}}))
     if world > 1:
         dist.barrier()

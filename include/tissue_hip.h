@@ -51,6 +51,7 @@ TIP_API int tip_malloc(void **dptr, size_t bytes);
 TIP_API int tip_free(void *dptr);
 TIP_API int tip_memcpy_h2d(void *dst, const void *src, size_t bytes);
 TIP_API int tip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+TIP_API int tip_memcpy_d2d(void *dst, const void *src, size_t bytes);   /* asynchronous, calling thread's stream */
 TIP_API int tip_memset(void *dst, int value, size_t bytes);
 TIP_API int tip_sync(void);                       /* wait for this thread's stream */
 
@@ -75,7 +76,7 @@ TIP_API int tip_gaussian3d_f32(const float *in, float *out, int z, int y, int x,
                                double sz, double sy, double sx, double truncate);
 TIP_API int tip_gaussian2d_f64(const double *in, double *out, int y, int x, double sy, double sx, double truncate);
 
-/* ---- surface projection: sp.py:17-85 (bin_size==1, build_manifold=False path) --------------- */
+/* ---- surface projection: sp.py:17-85 (build_manifold=False) ---------------------------------- */
 /* czyx: uint16 (C,Z,Y,X).  [zlo,zhi) is the z slice sp.py:30-31 takes when max_z>0 (else 0,Z).   */
 /* taps: scipy taps for sigma 0.5 (5), 1 (9), 2 (17), 30 (241); pass NULL to have them built with */
 /* libm.  proj: float64 (C,Y,X) (sp.py:74 np.zeros -> float64); zmap: int64 (Y,X) = min_z+argmax. */
@@ -87,6 +88,18 @@ TIP_API int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x
                                 int ref_ch, int airyscan, int atoh_shift,
                                 const double *t05, const double *t1, const double *t2, const double *t30,
                                 double *proj, int64_t *zmap);
+/* sp.py:39-65, bin_size > 1: the score is reduced over bin x bin blocks (skimage block_reduce with */
+/* np.mean / np.var, numpy's float32 summation order) and resized back (skimage.transform.resize,   */
+/* order 1) before the argmax.  method: 0 'max_averages', 1 'max_std', 2 'multi_channel' (block     */
+/* variance of the reference channel x block mean of channel (ref_ch+1)%c).  bin_size 1..128.       */
+TIP_API int tip_project_u16_binned(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z,
+                                   int ref_ch, int method, int bin_size, int airyscan, int atoh_shift,
+                                   const double *t05, const double *t1, const double *t2, const double *t30,
+                                   double *proj, int64_t *zmap);
+TIP_API int tip_project_u16_binned_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z,
+                                       int ref_ch, int method, int bin_size, int airyscan, int atoh_shift,
+                                       const double *t05, const double *t1, const double *t2, const double *t30,
+                                       double *proj, int64_t *zmap);
 
 /* ---- rank filters ---------------------------------------------------------------------------- */
 /* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */

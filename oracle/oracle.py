@@ -136,12 +136,110 @@ def put_channel_axis_first(image, axes):
     return image, tuple(np.arange(len(axes)))
 
 
+def _row_sum_f32(cols):
+    """numpy's float32 add.reduce along a contiguous axis (the inner loop of block_reduce's np.mean / np.var):
+    pairwise_sum (numpy/core/src/umath/loops_utils.h.src) over all n elements -- a plain running sum below 8 elements,
+    else eight running partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the tail added one by one
+    (blocks of at most 128 elements).  Pinned empirically against numpy 1.26.4 and 2.2.6.  `cols`: the elements."""
+    m = len(cols)
+    if m > 128:
+        raise NotImplementedError("oracle: block sizes up to 128")
+    if m < 8:
+        res = cols[0].copy()
+        for x in cols[1:]:
+            res = res + x
+        return res
+    r = [cols[j].copy() for j in range(8)]
+    i = 8
+    while i < m - (m % 8):
+        for j in range(8):
+            r[j] = r[j] + cols[i + j]
+        i += 8
+    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+    while i < m:
+        res = res + cols[i]
+        i += 1
+    return res
+
+
+def _blocks(a, b):
+    """skimage.measure.block_reduce's view: (Z, Y, X) float32 zero-padded to multiples of b -> (Z, Yb, b, Xb, b)."""
+    a = np.asarray(a, np.float32)
+    Z, Y, X = a.shape
+    Yp, Xp = -(-Y // b) * b, -(-X // b) * b
+    pad = np.zeros((Z, Yp, Xp), np.float32)
+    pad[:, :Y, :X] = a
+    return pad.reshape(Z, Yp // b, b, Xp // b, b)
+
+
+def _block_sum(blk):
+    """np.add.reduce of a (1, b, b) block in numpy's nditer order: every row of the block (contiguous in x) is reduced by
+    the inner loop, the row sums are accumulated one after the other (pinned empirically against numpy 1.26.4)."""
+    b = blk.shape[2]
+    acc = None
+    for r in range(b):
+        row = _row_sum_f32([blk[:, :, r, :, c] for c in range(b)])
+        acc = row if acc is None else acc + row
+    return acc
+
+
+def block_mean(a, b):
+    """block_reduce(a, (1, b, b), func=np.mean) (sp.py:41,50), float32."""
+    blk = _blocks(a, b)
+    return _block_sum(blk) / np.float32(b * b)
+
+
+def block_var(a, b):
+    """block_reduce(a, (1, b, b), func=np.var) (sp.py:43,49): numpy's _var in float32 -- mean, squared deviations, mean."""
+    blk = _blocks(a, b)
+    mean = _block_sum(blk) / np.float32(b * b)
+    dev = blk - mean[:, :, None, :, None]
+    return _block_sum(dev * dev) / np.float32(b * b)
+
+
+def _mirror_axis(n_in, n_out):
+    """Per output index along one axis: the two input indices and weights of skimage.transform.resize(order=1,
+    mode='reflect') -> scipy.ndimage.map_coordinates(order=1, mode='mirror') (skimage/transform/_warps.py:95-195):
+    coordinate factor*(i+0.5)-0.5 in float64, mirrored at the ends, weights (1 - t, 1 - (1 - t))."""
+    factor = np.float64(n_in) / np.float64(n_out)
+    c = factor * (np.arange(n_out) + 0.5) - 0.5
+    if n_in <= 1:
+        z = np.zeros(n_out, np.int64)
+        return z, z, np.ones(n_out), np.zeros(n_out)
+    c = np.where(c < 0, -c, c)                      # |c| < 0.5 below zero: mirror about 0
+    i0 = np.floor(c).astype(np.int64)
+    t = c - np.floor(c)
+    i1 = i0 + 1
+    i1 = np.where(i1 >= n_in, 2 * n_in - 2 - i1, i1)  # beyond the last sample: mirror about n-1
+    w0 = 1.0 - t
+    w1 = 1.0 - w0
+    return i0, i1, w0, w1
+
+
+def resize_linear(a, out_yx):
+    """skimage.transform.resize(a.astype('float32'), (Z, Y, X)) for a (Z, Yb, Xb) array (sp.py:58): the z factor is 1,
+    so every plane is interpolated bilinearly; scipy accumulates the four corner terms in float64 in the order
+    (y0,x0), (y0,x1), (y1,x0), (y1,x1), each as (v * wy) * wx, and rounds to float32."""
+    a = np.asarray(a, np.float32).astype(np.float64)
+    Y, X = out_yx
+    y0, y1, wy0, wy1 = _mirror_axis(a.shape[1], Y)
+    x0, x1, wx0, wx1 = _mirror_axis(a.shape[2], X)
+    wy0, wy1 = wy0[None, :, None], wy1[None, :, None]
+    wx0, wx1 = wx0[None, None, :], wx1[None, None, :]
+    r0, r1 = a[:, y0, :], a[:, y1, :]
+    t = (r0[:, :, x0] * wy0) * wx0
+    t = t + (r0[:, :, x1] * wy0) * wx1
+    t = t + (r1[:, :, x0] * wy1) * wx0
+    t = t + (r1[:, :, x1] * wy1) * wx1
+    return t.astype(np.float32)
+
+
 def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, max_z=0,
                                   method="max_averages", bin_size=1, airyscan=True, z_map=False,
                                   atoh_shift=0, build_manifold=False):
-    """sp.py:17-85, bin_size == 1 / build_manifold False path (the only one BASELINE configs use)."""
-    if bin_size != 1 or build_manifold:
-        raise NotImplementedError("oracle covers bin_size=1, build_manifold=False")
+    """sp.py:17-85 (build_manifold False)."""
+    if build_manifold:
+        raise NotImplementedError("oracle: build_manifold=False")
     if axes.find("T") >= 0:
         time_point = time_point.reshape(time_point.shape[1:])
         image, _ = put_channel_axis_first(time_point, axes[1:])
@@ -162,7 +260,22 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
         ch[ch > p95_32] = p95_32
     ch = blur_image(ch, (0.5, 1, 1))
     z_size, y_size, x_size = image.shape[-3:]
-    score = blur_image(ch, (0.5, 30, 30))
+    if bin_size > 1:
+        if method == "max_averages":
+            score = block_mean(blur_image(ch, (0.5, 30, 30)), bin_size)
+        elif method == "max_std":
+            score = block_var(ch, bin_size)
+        elif method == "multi_channel":
+            atoh = np.copy(image[(reference_channel + 1) % image.shape[0]])
+            a95 = np.float32(percentile_linear(atoh, 95))          # all voxels here, zeros included (sp.py:46)
+            atoh[atoh > a95] = a95
+            atoh = blur_image(atoh, (0.5, 1, 1))
+            score = block_mean(blur_image(atoh, (0.5, 30, 30)), bin_size) * block_var(ch, bin_size)
+        else:
+            raise TypeError("exceptions must derive from BaseException")   # `raise "No such method"` (sp.py:53)
+        score = resize_linear(score, (y_size, x_size))
+    else:
+        score = blur_image(ch, (0.5, 30, 30))
     chosen_z = min_z + np.argmax(score, axis=0)
     chosen_z_atoh = np.copy(chosen_z) if atoh_shift == 0 else np.clip(chosen_z + atoh_shift, 0, score.shape[0])
     mask = np.zeros((z_size, y_size * x_size), np.float32)

@@ -100,6 +100,52 @@ def test_projection_golden(mods, golden, case):
     np.testing.assert_allclose(proj, g[case + "_proj"], rtol=1e-5, atol=0)
 
 
+BINNED_CASES = {"avg10": dict(method="max_averages", bin_size=10), "std4": dict(method="max_std", bin_size=4),
+                "multi10": dict(method="multi_channel", bin_size=10),
+                "avg7_shift": dict(method="max_averages", bin_size=7, atoh_shift=1)}
+
+
+@pytest.mark.parametrize("tag", sorted(BINNED_CASES))
+def test_projection_binned_golden(mods, golden, tag):
+    """P4' (sp.py:39-65): bin_size > 1 with each score method, against the reference's own outputs."""
+    _, sp, _ = mods
+    g = golden("projection_binned")
+    p, z = sp.time_point_surface_projection(g["g_stack"][None].copy(), "TCZYX", 0, airyscan=False, z_map=True,
+                                            **BINNED_CASES[tag])
+    assert p.dtype == np.float64 and z.dtype == np.int64
+    assert int((z != g["g_%s_zmap" % tag]).sum()) == 0
+    np.testing.assert_array_equal(p, g["g_%s_proj" % tag])
+
+
+def test_projection_binned_three_channels_airyscan_golden(mods, golden):
+    _, sp, _ = mods
+    g = golden("projection_binned")
+    p, z = sp.time_point_surface_projection(g["h_stack"].copy(), "CZYX", 2, airyscan=True, z_map=True,
+                                            method="multi_channel", bin_size=16)
+    assert int((z != g["h_multi16_zmap"]).sum()) == 0
+    np.testing.assert_array_equal(p, g["h_multi16_proj"])
+    with pytest.raises(TypeError):      # sp.py:53 raises a str -> TypeError (golden bad_method_error)
+        sp.time_point_surface_projection(g["h_stack"].copy(), "CZYX", 0, airyscan=True, method="nope", bin_size=2)
+
+
+@pytest.mark.parametrize("method,bin_size,shape", [("max_averages", 10, (12, 250, 333)), ("max_std", 3, (7, 129, 131)),
+                                                   ("multi_channel", 16, (9, 200, 260)), ("max_std", 128, (5, 300, 140)),
+                                                   ("multi_channel", 2, (6, 64, 64))])
+def test_projection_binned_vs_oracle(mods, method, bin_size, shape):
+    """Ragged shapes and bin sizes (block rows shorter / longer than numpy's 8-way pairwise threshold, frames that are
+    not multiples of the bin, a bin larger than half the frame) against the oracle."""
+    _, sp, orc = mods
+    from tissue_image_processing_amd import synthetic
+    Z, Y, X = shape
+    st = synthetic.make_stack(Z, Y, X, seed=77 + bin_size)
+    p_ref, z_ref = orc.time_point_surface_projection(st.copy(), "CZYX", 1, airyscan=False, z_map=True, method=method,
+                                                     bin_size=bin_size)
+    p, z = sp.time_point_surface_projection(st.copy(), "CZYX", 1, airyscan=False, z_map=True, method=method,
+                                            bin_size=bin_size)
+    assert int((z != z_ref).sum()) == 0
+    np.testing.assert_array_equal(p, p_ref)
+
+
 def test_projection_vs_oracle_config1(mods):
     """BASELINE config[0]-like case (512x512, z=10) against the oracle on the same seeded stack."""
     _, sp, orc = mods

@@ -39,6 +39,12 @@ def test_world2_equals_world1(tmp_path):
     for t in range(int(a["n"])):
         np.testing.assert_array_equal(a["ids_%d" % t], b["ids_%d" % t])
         np.testing.assert_array_equal(a["area_%d" % t], b["area_%d" % t])
+        np.testing.assert_array_equal(a["eids_%d" % t], b["eids_%d" % t])
+    # drift estimated by each frame's owner from the neighbour rank's plane: identical in both runs, and close to the
+    # synthetic movie's global motion (0.5, -0.3) px/frame undone (the sites also random-walk, so only roughly)
+    np.testing.assert_array_equal(a["est"], b["est"])
+    print("estimated drifts:", a["est"].tolist())
+    assert np.all(np.abs(a["est"][1:] - np.array([-0.5, 0.3])) < 1.0)
 
 
 def test_watershed_fallback_paths_agree(monkeypatch):

@@ -70,6 +70,43 @@ def test_projection_no_channel_axis_error(golden):
         orc.time_point_surface_projection(np.zeros((4, 8, 8), np.uint16), "ZYX", 0, airyscan=False)
 
 
+def test_block_reduce_and_resize_pieces(golden):
+    """P4' building blocks against skimage's own block_reduce(np.mean / np.var) and transform.resize outputs."""
+    g = golden("projection_binned")
+    vol = g["vol"]
+    for b in (2, 3, 7, 10, 16, 20):
+        np.testing.assert_array_equal(orc.block_mean(vol, b), g["mean_b%d" % b])
+        np.testing.assert_array_equal(orc.block_var(vol, b), g["var_b%d" % b])
+    np.testing.assert_array_equal(orc.resize_linear(g["small"], (47, 53)), g["small_resized"])
+    np.testing.assert_array_equal(orc.resize_linear(g["small"][:, :1, :2], (9, 11)), g["small_resized_b"])
+
+
+BINNED_CASES = {"avg10": dict(method="max_averages", bin_size=10), "std4": dict(method="max_std", bin_size=4),
+                "multi10": dict(method="multi_channel", bin_size=10),
+                "avg7_shift": dict(method="max_averages", bin_size=7, atoh_shift=1)}
+
+
+@pytest.mark.parametrize("tag", sorted(BINNED_CASES))
+def test_projection_binned(golden, tag):
+    """sp.py:39-65 (bin_size > 1): z-map and projection from the reference itself."""
+    g = golden("projection_binned")
+    p, z = orc.time_point_surface_projection(g["g_stack"][None].copy(), "TCZYX", 0, airyscan=False, z_map=True,
+                                             **BINNED_CASES[tag])
+    np.testing.assert_array_equal(z, g["g_%s_zmap" % tag])
+    np.testing.assert_array_equal(p, g["g_%s_proj" % tag])
+
+
+def test_projection_binned_three_channels_airyscan(golden):
+    g = golden("projection_binned")
+    p, z = orc.time_point_surface_projection(g["h_stack"].copy(), "CZYX", 2, airyscan=True, z_map=True,
+                                             method="multi_channel", bin_size=16)
+    np.testing.assert_array_equal(z, g["h_multi16_zmap"])
+    np.testing.assert_array_equal(p, g["h_multi16_proj"])
+    assert str(g["bad_method_error"]) == "TypeError"
+    with pytest.raises(TypeError):
+        orc.time_point_surface_projection(g["h_stack"].copy(), "CZYX", 0, airyscan=True, method="nope", bin_size=2)
+
+
 def test_rank_filters(golden):
     g = golden("rank_filters")
     lab, img = g["lab"], g["img"]

@@ -37,6 +37,11 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, sp
             raise NotImplementedError("MI355X phase correlation takes extents in [2, 4096] (got %dx%d)" % (ny, nx))
     out = (ctypes.c_int64 * 4)()
     _lib.check(_lib.lib().tip_phase_correlation(_lib.ptr(a), _lib.ptr(b), dt, ny, nx, int(upsample_factor), out))
+    return _finish_shifts(out, ny, nx, upsample_factor), None, None
+
+
+def _finish_shifts(out, ny, nx, upsample_factor):
+    """skimage's closing arithmetic on the two integer peaks the library returns (whole-pixel peak, upsampled-DFT peak)."""
     shape = np.array([ny, nx])
     shifts = np.array([out[0], out[1]], dtype=np.float64)
     midpoints = np.array([np.fix(s / 2) for s in shape])
@@ -47,4 +52,13 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, sp
         dftshift = np.fix(np.ceil(uf * 1.5) / 2.0)
         maxima = np.array([out[2], out[3]], dtype=np.float64) - dftshift
         shifts = shifts + maxima / uf
-    return shifts, None, None
+    return shifts
+
+
+def phase_cross_correlation_dev(ref_ptr, mov_ptr, ny, nx, upsample_factor=100, dtype="float64"):
+    """The same on two device-resident (ny, nx) planes (device addresses); returns the shift array."""
+    dt = {"float32": 0, "float64": 1, "uint16": 3}[dtype]
+    out = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.lib().tip_phase_correlation_dev(_lib.dptr(ref_ptr), _lib.dptr(mov_ptr), dt, int(ny), int(nx),
+                                                    int(upsample_factor), out))
+    return _finish_shifts(out, ny, nx, upsample_factor)

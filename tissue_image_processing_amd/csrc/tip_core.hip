@@ -240,6 +240,14 @@ int tip_memcpy_d2h(void *dst, const void *src, size_t bytes)
     return TIP_OK;
 }
 
+int tip_memcpy_d2d(void *dst, const void *src, size_t bytes)   // asynchronous on the calling thread's stream
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    TIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c.stream));
+    return TIP_OK;
+}
+
 int tip_memset(void *dst, int value, size_t bytes)
 {
     Ctx &c = ctx();

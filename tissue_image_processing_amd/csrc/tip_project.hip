@@ -66,12 +66,13 @@ __global__ void __launch_bounds__(1024) k_hist_u16(const uint16_t *__restrict__ 
 }
 
 // np.percentile(nonzero, 95) with numpy 1.26 arithmetic (see oracle.percentile_linear): one block.
-__global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long *__restrict__ hist, ClipInfo *out)
+// (with_zero: over all voxels, zeros included -- the second channel of method 'multi_channel', sp.py:46)
+__global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long *__restrict__ hist, ClipInfo *out, int with_zero)
 {
     __shared__ unsigned long long part[1024];
     unsigned long long s = 0;
     for (int b = threadIdx.x * 64; b < threadIdx.x * 64 + 64; ++b)
-        if (b > 0) s += hist[b];
+        if (b > 0 || with_zero) s += hist[b];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long 
             cum += part[chunk];
         }
         for (int b = chunk * 64; b < chunk * 64 + 64; ++b) {
-            if (b == 0) continue;
+            if (b == 0 && !with_zero) continue;
             cum += hist[b];
             if (cum > (unsigned long long)k) return b;
         }
@@ -538,6 +539,110 @@ __global__ void __launch_bounds__(256) k_emit_zmaps(const int *__restrict__ best
     zsel_atoh[p] = ca;
 }
 
+// ---- P4': bin_size > 1 (sp.py:39-65) -------------------------------------------------------------------------------
+// skimage.measure.block_reduce(vol, (1, b, b), np.mean / np.var) in float32 with numpy's summation order: every row of
+// a block (b contiguous samples, zeros beyond the frame) goes through numpy's pairwise_sum -- a running sum below 8
+// elements, else eight running partial sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the tail -- and the row
+// sums are added up one after the other; mean = sum / float32(b*b); var = the same reduction of (x - mean)^2.
+__device__ __forceinline__ float pw_row_sum(const float *__restrict__ row, int b, int valid, float mean, bool sq)
+{
+    auto at = [&](int i) -> float {
+        const float v = i < valid ? row[i] : 0.f;
+        if (!sq) return v;
+        const float d = v - mean;
+        return d * d;
+    };
+    if (b < 8) {
+        float res = at(0);
+        for (int i = 1; i < b; ++i) res += at(i);
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = at(j);
+    int i = 8;
+    for (; i < b - (b % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += at(i + j);
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < b; ++i) res += at(i);
+    return res;
+}
+
+template <bool VAR>
+__global__ void __launch_bounds__(256) k_block_reduce(const float *__restrict__ vol, float *__restrict__ out, int Z, int Y, int X,
+                                                      int b, int Yb, int Xb)
+{
+    const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (long)Z * Yb * Xb) return;
+    const int xb = (int)(o % Xb), yb = (int)((o / Xb) % Yb), z = (int)(o / ((long)Xb * Yb));
+    const int x0 = xb * b, y0 = yb * b;
+    const int valid = min(b, X - x0);
+    const float *base = vol + ((long)z * Y + y0) * X + x0;
+    const float cnt = (float)(b * b);
+    float acc = 0.f;
+    for (int r = 0; r < b; ++r) {
+        const float row = pw_row_sum(base + (long)r * X, b, y0 + r < Y ? valid : 0, 0.f, false);
+        acc = r == 0 ? row : acc + row;
+    }
+    const float mean = acc / cnt;
+    if (!VAR) { out[o] = mean; return; }
+    for (int r = 0; r < b; ++r) {
+        const float row = pw_row_sum(base + (long)r * X, b, y0 + r < Y ? valid : 0, mean, true);
+        acc = r == 0 ? row : acc + row;
+    }
+    out[o] = acc / cnt;
+}
+
+__global__ void __launch_bounds__(256) k_mul_f32(float *__restrict__ a, const float *__restrict__ b, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] * b[i];
+}
+
+// skimage.transform.resize(score, (Z, Y, X)) (order 1, mode 'reflect' -> scipy map_coordinates 'mirror'; the z factor is
+// 1) fused with the first-maximum argmax over z.  One axis: coordinate f * (i + 0.5) - 0.5 in float64 with f = n_in /
+// n_out, mirrored at both ends, weights (1 - t, 1 - (1 - t)); scipy adds the four corner terms (v * wy) * wx in float64 in
+// the order (y0,x0), (y0,x1), (y1,x0), (y1,x1) and rounds to float32.
+struct LinTap { int i0, i1; double w0, w1; };
+__device__ __forceinline__ LinTap lin_tap(int i, int n_in, int n_out)
+{
+    LinTap t;
+    if (n_in <= 1) { t.i0 = 0; t.i1 = 0; t.w0 = 1.0; t.w1 = 0.0; return t; }
+    const double f = (double)n_in / (double)n_out;
+    double c = f * ((double)i + 0.5) - 0.5;
+    if (c < 0.0) c = -c;
+    const double fl = floor(c);
+    t.i0 = (int)fl;
+    t.i1 = t.i0 + 1;
+    if (t.i1 >= n_in) t.i1 = 2 * n_in - 2 - t.i1;
+    t.w0 = 1.0 - (c - fl);
+    t.w1 = 1.0 - t.w0;
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_resize_argmax(const float *__restrict__ binned, int Z, int Yb, int Xb, int Y, int X,
+                                                       int *__restrict__ best_z)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const LinTap ty = lin_tap(y, Yb, Y), tx = lin_tap(x, Xb, X);
+    float best = 0.f;
+    int bi = 0;
+    for (int z = 0; z < Z; ++z) {
+        const float *pl = binned + (long)z * Yb * Xb;
+        const double v00 = pl[(long)ty.i0 * Xb + tx.i0], v01 = pl[(long)ty.i0 * Xb + tx.i1];
+        const double v10 = pl[(long)ty.i1 * Xb + tx.i0], v11 = pl[(long)ty.i1 * Xb + tx.i1];
+        double t = (v00 * ty.w0) * tx.w0;
+        t += (v01 * ty.w0) * tx.w1;
+        t += (v10 * ty.w1) * tx.w0;
+        t += (v11 * ty.w1) * tx.w1;
+        const float s = (float)t;
+        if (z == 0 || s > best) { best = s; bi = z; }
+    }
+    best_z[(long)y * X + x] = bi;
+}
+
 static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
 {
     double buf[256];
@@ -549,7 +654,7 @@ static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
     return make_taps(t, given, expect);
 }
 
-int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int zhi, int min_z, int ref_ch,
+int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int zhi, int min_z, int ref_ch, int method, int bin,
                 int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
                 const double *t30, double *proj, int64_t *zmap)
 {
@@ -583,27 +688,63 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
     TIP_HIP(hipMemsetAsync(err, 0, sizeof(int), c.stream));
     TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, ref, V, airyscan, hist);
-    TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip);
+    TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip, 0);
 
     const bool fast = (X % 4 == 0) && !getenv("TIP_PROJECT_GENERIC");
-    if (fast) {
-        // P3: (0.5, 1, 1) and P4's z pass with register-sliding kernels (each input loaded once per thread)
-        Src4U16Clip su{ref, airyscan, &clip->p95, &clip->has};
-        TIP_LAUNCH("zpass_u16clip_x4", (k_zpass_r2_x4<Src4U16Clip>), dim3(cdiv(P / 4, 256)), dim3(256), 0, su, A, Zs, P, k05);
-        TIP_LAUNCH("ypass_slide_r4", (k_ypass_slide<float, 4, 4>), dim3(cdiv(X, 256), cdiv(Y, 36), Zs), dim3(256), 0, (const float *)A, B, Y,
-                   X, k1);
-        TIP_LAUNCH("xpass_slide_r4", (k_xpass_slide<float, 4>), dim3(cdiv(cdiv(X, 8), 256), Y, Zs), dim3(256), 0, (const float *)B, A, Y, X,
-                   k1);
-        Src4F32 sf{A};
-        TIP_LAUNCH("zpass_f32_x4", (k_zpass_r2_x4<Src4F32>), dim3(cdiv(P / 4, 256)), dim3(256), 0, sf, B, Zs, P, k05);
-    } else {
-        LoadU16Clip ld{ref, P, (long)X, airyscan, clip};
+    // P3: (0.5, 1, 1) of the clipped channel -> A_, then P4's z pass (0.5) of that -> B_
+    auto short_blur = [&](const uint16_t *src, ClipInfo *ci, float *A_, float *B_) -> int {
+        if (fast) {   // register-sliding kernels (each input loaded once per thread)
+            Src4U16Clip su{src, airyscan, &ci->p95, &ci->has};
+            TIP_LAUNCH("zpass_u16clip_x4", (k_zpass_r2_x4<Src4U16Clip>), dim3(cdiv(P / 4, 256)), dim3(256), 0, su, A_, Zs, P, k05);
+            TIP_LAUNCH("ypass_slide_r4", (k_ypass_slide<float, 4, 4>), dim3(cdiv(X, 256), cdiv(Y, 36), Zs), dim3(256), 0,
+                       (const float *)A_, B_, Y, X, k1);
+            TIP_LAUNCH("xpass_slide_r4", (k_xpass_slide<float, 4>), dim3(cdiv(cdiv(X, 8), 256), Y, Zs), dim3(256), 0, (const float *)B_,
+                       A_, Y, X, k1);
+            Src4F32 sf{A_};
+            TIP_LAUNCH("zpass_f32_x4", (k_zpass_r2_x4<Src4F32>), dim3(cdiv(P / 4, 256)), dim3(256), 0, sf, B_, Zs, P, k05);
+            return TIP_OK;
+        }
+        LoadU16Clip ld{src, P, (long)X, airyscan, ci};
         dim3 grid(cdiv(X, 256), Y, Zs), block(256);
-        TIP_LAUNCH("corr_z_u16clip", (k_corr_generic<float, 0, LoadU16Clip>), grid, block, 0, ld, A, Zs, Y, X, k05);
-        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 1, k1, 0))) return rc;
-        if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 2, k1, 0))) return rc;
-        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 0, k05, 0))) return rc;
-    }
+        TIP_LAUNCH("corr_z_u16clip", (k_corr_generic<float, 0, LoadU16Clip>), grid, block, 0, ld, A_, Zs, Y, X, k05);
+        int r2;
+        if ((r2 = correlate1d_dev(A_, B_, 0, Zs, Y, X, 1, k1, 0))) return r2;
+        if ((r2 = correlate1d_dev(B_, A_, 0, Zs, Y, X, 2, k1, 0))) return r2;
+        return correlate1d_dev(A_, B_, 0, Zs, Y, X, 0, k05, 0);
+    };
+    if ((rc = short_blur(ref, clip, A, B))) return rc;
+    if (bin > 1) {
+        // P4' (sp.py:39-65): score on bin x bin blocks, resized back to the frame for the argmax
+        const int Yb = cdiv(Y, bin), Xb = cdiv(X, bin);
+        const long nb = (long)Zs * Yb * Xb;
+        float *S1 = ws.get<float>(nb);
+        int *bestz = ws.get<int>(P);
+        if (!S1 || !bestz) return TIP_ERR_NOMEM;
+        if (method == 0) {          // max_averages: block mean of the (exact) (0.5, 30, 30) blur
+            if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
+            if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
+            TIP_LAUNCH("block_mean", (k_block_reduce<false>), dim3(cdiv(nb, 256)), dim3(256), 0, (const float *)B, S1, Zs, Y, X, bin, Yb, Xb);
+        } else {                    // max_std / multi_channel: block variance of the (0.5, 1, 1) blur
+            TIP_LAUNCH("block_var", (k_block_reduce<true>), dim3(cdiv(nb, 256)), dim3(256), 0, (const float *)A, S1, Zs, Y, X, bin, Yb, Xb);
+            if (method == 2) {      // times the block mean of the next channel's (0.5, 30, 30) blur (sp.py:45-51)
+                const uint16_t *other = czyx + ((long)((ref_ch + 1) % C) * Z + zlo) * P;
+                float *S2 = ws.get<float>(nb);
+                ClipInfo *clip2 = ws.get<ClipInfo>(1);
+                if (!S2 || !clip2) return TIP_ERR_NOMEM;
+                TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
+                TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, other, V, airyscan, hist);
+                TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip2, 1);
+                if ((rc = short_blur(other, clip2, A, B))) return rc;
+                if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
+                if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
+                TIP_LAUNCH("block_mean", (k_block_reduce<false>), dim3(cdiv(nb, 256)), dim3(256), 0, (const float *)B, S2, Zs, Y, X, bin, Yb, Xb);
+                TIP_LAUNCH("mul_f32", k_mul_f32, dim3(cdiv(nb, 256)), dim3(256), 0, S1, (const float *)S2, nb);
+            }
+        }
+        TIP_LAUNCH("resize_argmax", k_resize_argmax, dim3(cdiv(X, 256), Y), dim3(256), 0, (const float *)S1, Zs, Yb, Xb, Y, X, bestz);
+        TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
+                   zsel_a, zmap, err);
+    } else {
     // P4 + P5: (0.5, 30, 30) score and its argmax
     const bool certified = fast && Zs <= 64 && !getenv("TIP_PROJECT_EXACT_SCORE");
     if (certified) {
@@ -639,6 +780,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         TIP_LAUNCH("argmax_z", k_argmax_z, dim3(cdiv(P, 256)), dim3(256), 0, B, Zs, P, min_z, atoh_shift, zsel, zsel_a, zmap,
                    err);
     }
+    }   // bin == 1
     // P6/P7 z pass as a Zs x Zs table (sigma 1 -> 9 taps), built with the same correlate kernel
     TIP_LAUNCH("identity", k_identity, dim3(cdiv((long)Zs * Zs, 256)), dim3(256), 0, ident, Zs);
     if ((rc = correlate1d_dev(ident, table, 0, Zs, Zs, 1, 0, k1, 1))) return rc;
@@ -678,16 +820,9 @@ using namespace tip;
 
 extern "C" {
 
-int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
-                        int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+static int project_host(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch, int method,
+                        int bin, int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
                         const double *t30, double *proj, int64_t *zmap)
-{
-    return project_dev(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
-}
-
-int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
-                    int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
-                    const double *t30, double *proj, int64_t *zmap)
 {
     Ctx &cx = ctx();
     if (!cx.stream) return TIP_ERR_HIP;
@@ -700,12 +835,51 @@ int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, i
     int64_t *dz = ws.get<int64_t>(P);
     if (!din || !dproj || !dz) return TIP_ERR_NOMEM;
     TIP_HIP(hipMemcpyAsync(din, czyx, nin * 2, hipMemcpyHostToDevice, cx.stream));
-    int rc = project_dev(din, c, z, y, x, zlo, zhi, min_z, ref_ch, airyscan, atoh_shift, t05, t1, t2, t30, dproj, dz);
+    int rc = project_dev(din, c, z, y, x, zlo, zhi, min_z, ref_ch, method, bin, airyscan, atoh_shift, t05, t1, t2, t30, dproj, dz);
     if (rc) return rc;
     TIP_HIP(hipMemcpyAsync(proj, dproj, (size_t)c * P * 8, hipMemcpyDeviceToHost, cx.stream));
     if (zmap) TIP_HIP(hipMemcpyAsync(zmap, dz, P * 8, hipMemcpyDeviceToHost, cx.stream));
     TIP_HIP(hipStreamSynchronize(cx.stream));
     return TIP_OK;
+}
+
+static int check_binned(int method, int bin)
+{
+    if (method < 0 || method > 2) return fail(TIP_ERR_ARG, "projection: method %d (0 max_averages, 1 max_std, 2 multi_channel)", method);
+    if (bin < 1 || bin > 128) return fail(TIP_ERR_UNSUPPORTED, "projection: bin_size %d (1..128 supported)", bin);
+    return TIP_OK;
+}
+
+int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                        int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                        const double *t30, double *proj, int64_t *zmap)
+{
+    return project_dev(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, 0, 1, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                    int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                    const double *t30, double *proj, int64_t *zmap)
+{
+    return project_host(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, 0, 1, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+int tip_project_u16_binned_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                               int method, int bin_size, int airyscan, int atoh_shift, const double *t05, const double *t1,
+                               const double *t2, const double *t30, double *proj, int64_t *zmap)
+{
+    int rc = check_binned(method, bin_size);
+    if (rc) return rc;
+    return project_dev(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, method, bin_size, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+int tip_project_u16_binned(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                           int method, int bin_size, int airyscan, int atoh_shift, const double *t05, const double *t1,
+                           const double *t2, const double *t30, double *proj, int64_t *zmap)
+{
+    int rc = check_binned(method, bin_size);
+    if (rc) return rc;
+    return project_host(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, method, bin_size, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
 }
 
 }  // extern "C"

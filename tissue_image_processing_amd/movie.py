@@ -9,6 +9,12 @@ collective.  The one exchange step is track stitching (tissue_info.track_cells_i
   3. the resulting index arrays (one int per cell) are gathered to rank 0 (RCCL gather = grouped send/recv over
      xGMI, a direct all-to-one, KBs per frame), which runs the sequential id propagation.
 
+With `estimate_drift=True` the frame-to-frame drift (Tissue.update_drift, ti.py:1982-2035) is computed inside the
+sharded driver as well: the owner of frame t needs frame t-1's reference-channel projection, which lives on rank
+(t-1) % world -- one point-to-point transfer of a (Y, X) float64 plane per frame (33.5 MB at 2048^2, rank r -> r+1 over
+xGMI, all pairs at once) -- and runs the phase correlation next to its own plane.  `stitcher="linker"` replaces the
+label-lookup tracker by the trackpy-model linker (ti.py:1881-1933, linking.FrameLinker) on rank 0.
+
 `backend` supplies the per-frame compute so the same driver runs on GPUs (GpuFrameBackend) and, for the
 multi-process CPU tests, on a stand-in backend with the gloo process group.
 """
@@ -16,13 +22,17 @@ import numpy as np
 
 
 class GpuFrameBackend(object):
-    """Per-frame compute on this rank's MI355X through FramePipeline; label maps stay resident per owned frame."""
+    """Per-frame compute on this rank's MI355X through FramePipeline.  What later stages need stays resident per owned
+    frame: the int32 label map (tracker look-ups) and, when drift is estimated, the reference channel's projection plane
+    -- both kept with device-to-device copies.  The planes are torch tensors so that RCCL can send them as they are."""
 
-    def __init__(self, C, Z, Y, X, device=None, **kw):
+    def __init__(self, C, Z, Y, X, device=None, keep_planes=False, **kw):
         from .pipeline import FramePipeline
         self.pipe = FramePipeline(C, Z, Y, X, device=device, **kw)
         self.Y, self.X = Y, X
+        self.keep_planes = keep_planes
         self.labels = {}   # frame -> DeviceBuffer (int32 label map)
+        self.planes = {}   # frame -> torch tensor (Y, X) float64 on this GPU
 
     def process_frame(self, t, stack_u16):
         from . import _lib
@@ -30,13 +40,19 @@ class GpuFrameBackend(object):
         d_stack = p.upload_stack(stack_u16)
         p.project(d_stack)
         p.segment(0)
-        tab = p.cell_tables()
-        d_stack.free()
-        keep = _lib.DeviceBuffer(self.Y * self.X * 4)
-        _lib.check(p.lib.tip_sync())
-        lab = p.fetch_labels()
-        keep.upload(lab)
+        nbytes = self.Y * self.X * 4
+        keep = _lib.DeviceBuffer(nbytes)
+        _lib.check(p.lib.tip_memcpy_d2d(_lib.dptr(keep.ptr), _lib.dptr(p.d_labels.ptr), nbytes))
         self.labels[t] = keep
+        if self.keep_planes:
+            import torch
+            dev = torch.device("cuda", _lib.device_for_thread() or 0)
+            plane = torch.empty((self.Y, self.X), dtype=torch.float64, device=dev)
+            _lib.check(p.lib.tip_memcpy_d2d(_lib.dptr(plane.data_ptr()), _lib.dptr(p.d_proj.ptr + p.ref * self.Y * self.X * 8),
+                                            self.Y * self.X * 8))
+            self.planes[t] = plane
+        tab = p.cell_tables()          # (synchronises: the small per-cell arrays come to the host)
+        d_stack.free()
         area = tab["area"].astype(np.float64)
         with np.errstate(invalid="ignore", divide="ignore"):
             cy = tab["sumy"] / area
@@ -51,6 +67,24 @@ class GpuFrameBackend(object):
         _lib.check(self.pipe.lib.tip_lookup_max3_i32_dev(_lib.dptr(self.labels[t].ptr), self.Y, self.X, _lib.ptr(qy),
                                                           _lib.ptr(qx), qy.size, _lib.ptr(out)))
         return out
+
+    # -- drift (T2) ------------------------------------------------------------------------------------------
+    def plane(self, t):
+        return self.planes[t]
+
+    def empty_plane(self):
+        import torch
+        from . import _lib
+        return torch.empty((self.Y, self.X), dtype=torch.float64, device=torch.device("cuda", _lib.device_for_thread() or 0))
+
+    def drift(self, t, prev_plane):
+        """(row shift, column shift) that registers frame t onto frame t-1: Tissue.update_drift without a stage table
+        (ti.py:1982-2035 -> calculate_refine_drift with a zero coarse shift -> phase_cross_correlation(upsample 100))."""
+        import torch
+        from ._registration import phase_cross_correlation_dev
+        torch.cuda.current_stream(prev_plane.device).synchronize()      # the received plane is complete
+        sh = phase_cross_correlation_dev(prev_plane.data_ptr(), self.planes[t].data_ptr(), self.Y, self.X, 100)
+        return float(sh[0]), float(sh[1])
 
 
 def _all_gather_arrays(arrs, dist, world, device):
@@ -124,31 +158,99 @@ def propagate_ids(tables, lookups):
     return out
 
 
-def process_movie(n_frames, frame_source, backend, rank=0, world=1, dist=None, device="cpu", drifts=None):
+def exchange_planes(n_frames, mine, backend, rank, world, dist):
+    """Every owner of a frame t >= 1 gets frame t-1's plane: rank r sends its planes to rank (r+1) % world and receives
+    from (r-1) % world, all pairs at once (grouped isend/irecv: over RCCL each pair has its own xGMI link, no ring)."""
+    prev = {}
+    if world == 1:
+        for t in mine:
+            if t >= 1:
+                prev[t] = backend.plane(t - 1)
+        return prev
+    # gloo (the CPU test harness) moves host tensors only: device planes are staged through the host there; RCCL sends
+    # the device planes as they are
+    staged = dist.get_backend() == "gloo"
+    ops, landing = [], {}
+    for t in mine:                                   # increasing t on both sides: matching order per pair
+        if t + 1 < n_frames:
+            src = backend.plane(t)
+            ops.append(dist.P2POp(dist.isend, src.cpu() if staged and src.is_cuda else src, (rank + 1) % world))
+    for t in mine:
+        if t >= 1:
+            prev[t] = backend.empty_plane()
+            landing[t] = prev[t].cpu() if staged and prev[t].is_cuda else prev[t]
+            ops.append(dist.P2POp(dist.irecv, landing[t], (rank - 1) % world))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for t, buf in landing.items():
+        if buf is not prev[t]:
+            prev[t].copy_(buf)
+    return prev
+
+
+def link_ids(tables, drifts):
+    """stitcher="linker": track ids from the trackpy-model linker (ti.py:1881-1933) on rank 0: features are the present
+    rows' (cy, cx, area) shifted by the cumulative drift; id = particle + 1, absent rows 0."""
+    from .linking import FrameLinker, embed
+    linker = FrameLinker(search_range=100, adaptive_stop=10, adaptive_step=0.95, memory=3)
+    total = np.zeros(2)
+    out = []
+    for t, tb in enumerate(tables):
+        if t > 0:
+            total = total + np.asarray(drifts[t], dtype=np.float64)
+        present = np.flatnonzero(tb["area"] > 0)
+        particles = linker.link(embed(tb["cy"][present] + total[0], tb["cx"][present] + total[1], tb["area"][present]))
+        ids = np.zeros(tb["area"].size, np.int64)
+        ids[present] = np.asarray(particles, dtype=np.int64) + 1
+        out.append(ids)
+    return out
+
+
+def process_movie(n_frames, frame_source, backend, rank=0, world=1, dist=None, device="cpu", drifts=None,
+                  estimate_drift=False, stitcher="lookup"):
     """Runs the sharded pipeline.  frame_source(t) -> uint16 stack (or whatever backend.process_frame takes).
-    Returns on rank 0: (tables per frame, track ids per frame); on other ranks (None, None)."""
+    Returns on rank 0: (tables per frame, track ids per frame); on other ranks (None, None).  tables[t]["drift"] holds
+    the (row, column) drift used between frames t-1 and t (estimated by frame t's owner when estimate_drift)."""
     if drifts is None:
         drifts = np.zeros((n_frames, 2))
+    drifts = np.array(drifts, dtype=np.float64)
     mine = list(range(rank, n_frames, world))
     local = {t: backend.process_frame(t, frame_source(t)) for t in mine}
+    if estimate_drift:
+        prev = exchange_planes(n_frames, mine, backend, rank, world, dist)
+        for t in mine:
+            if t >= 1:
+                drifts[t] = backend.drift(t, prev.pop(t))
+    for t in mine:
+        local[t]["drift"] = drifts[t].copy()
     # 1. centroid tables everywhere
     if world > 1:
         payload = []
         for t in mine:
             tb = local[t]
-            payload += [np.array([t, tb["area"].size], np.float64), tb["area"].astype(np.float64), tb["cy"], tb["cx"]]
+            payload += [np.array([t, tb["area"].size, tb["drift"][0], tb["drift"][1]], np.float64),
+                        tb["area"].astype(np.float64), tb["cy"], tb["cx"]]
         gathered = _all_gather_arrays(payload, dist, world, device)
         tables = {}
         for flat in gathered:
             pos = 0
             while pos < flat.size:
                 t, n = int(flat[pos]), int(flat[pos + 1])
-                pos += 2
+                drift_t = flat[pos + 2:pos + 4].copy()
+                pos += 4
                 tables[t] = dict(area=flat[pos:pos + n].astype(np.int64), cy=flat[pos + n:pos + 2 * n],
-                                 cx=flat[pos + 2 * n:pos + 3 * n])
+                                 cx=flat[pos + 2 * n:pos + 3 * n], drift=drift_t)
                 pos += 3 * n
     else:
         tables = local
+    if stitcher == "linker":
+        if rank != 0:
+            return None, None
+        tabs = [tables[t] for t in range(n_frames)]
+        return tabs, link_ids(tabs, [tb["drift"] for tb in tabs])
+    if stitcher != "lookup":
+        raise ValueError("stitcher must be 'lookup' or 'linker'")
     # 2. owners look previous centroids up in their resident label maps
     my_lookups = {}
     for t in mine:

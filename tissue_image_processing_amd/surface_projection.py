@@ -1,9 +1,12 @@
 """Drop-in for time_point_surface_projection of the reference's surface_projection.py (sp.py:17-85) on MI355X.
 
 Signature, defaults, return types and error behaviour follow the reference; the arithmetic runs in
-libtissue_hip.so (tip_project_u16).  Covered: bin_size == 1 and build_manifold == False (what every BASELINE
-config and movie_surface_projection's default use); the bin_size > 1 / manifold variants are SURVEY.md 8(f) "next".
+libtissue_hip.so (tip_project_u16 / tip_project_u16_binned).  Covered: bin_size == 1 (what every BASELINE config and
+movie_surface_projection's default use) and bin_size > 1 with methods 'max_averages', 'max_std', 'multi_channel'
+(sp.py:39-65); build_manifold (the serial spiral of sp.py:87-165) is not.
 """
+
+_METHODS = {"max_averages": 0, "max_std": 1, "multi_channel": 2}
 import ctypes
 
 import numpy as np
@@ -17,8 +20,10 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
                                   build_manifold=False):
     if bin_size > 1 and method not in ("max_averages", "max_std", "multi_channel"):
         raise TypeError("exceptions must derive from BaseException")  # sp.py:53 raises a str
-    if bin_size > 1 or build_manifold:
-        raise NotImplementedError("MI355X path covers bin_size=1, build_manifold=False (SURVEY.md 8f rank 3)")
+    if build_manifold:
+        raise NotImplementedError("MI355X path covers build_manifold=False (SURVEY.md 8f rank 3)")
+    if bin_size > 128:
+        raise NotImplementedError("MI355X path covers bin_size <= 128")
     if axes.find("T") >= 0:
         time_point = time_point.reshape(time_point.shape[1:])
         image, _ = put_channel_axis_first(time_point, axes[1:])
@@ -48,9 +53,15 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
     proj = np.empty((C, Y, X), np.float64)
     zmap = np.empty((Y, X), np.int64)
     lib = _lib.lib()
-    rc = lib.tip_project_u16(_lib.ptr(image), C, Z, Y, X, int(zlo), int(zhi), int(min_z), int(reference_channel),
-                             1 if airyscan else 0, int(atoh_shift), _lib.ptr(t05), _lib.ptr(t1), _lib.ptr(t2),
-                             _lib.ptr(t30), _lib.ptr(proj), _lib.ptr(zmap))
+    if bin_size > 1:
+        rc = lib.tip_project_u16_binned(_lib.ptr(image), C, Z, Y, X, int(zlo), int(zhi), int(min_z), int(reference_channel),
+                                        _METHODS[method], int(bin_size), 1 if airyscan else 0, int(atoh_shift),
+                                        _lib.ptr(t05), _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(t30), _lib.ptr(proj),
+                                        _lib.ptr(zmap))
+    else:
+        rc = lib.tip_project_u16(_lib.ptr(image), C, Z, Y, X, int(zlo), int(zhi), int(min_z), int(reference_channel),
+                                 1 if airyscan else 0, int(atoh_shift), _lib.ptr(t05), _lib.ptr(t1), _lib.ptr(t2),
+                                 _lib.ptr(t30), _lib.ptr(proj), _lib.ptr(zmap))
     _lib.check(rc)
     if z_map:
         return proj, zmap

@@ -116,6 +116,46 @@ def gold_projection():
     return proj, proj_f
 
 
+def gold_projection_binned():
+    """P4' (sp.py:39-65): bin_size > 1 with the three score methods, plus the two third-party pieces they rest on
+    (skimage.measure.block_reduce with np.mean / np.var, skimage.transform.resize) on their own."""
+    from skimage.measure import block_reduce
+    from skimage.transform import resize
+    rng = np.random.default_rng(31)
+    out = {}
+    vol = (rng.random((3, 47, 53)) * 1000).astype(np.float32)
+    out["vol"] = vol
+    for b in (2, 3, 7, 10, 16, 20):
+        out["mean_b%d" % b] = block_reduce(vol, (1, b, b), func=np.mean)
+        out["var_b%d" % b] = block_reduce(vol, (1, b, b), func=np.var)
+    small = (rng.random((4, 5, 6)) * 10).astype(np.float32)
+    out["small"] = small
+    out["small_resized"] = resize(small.astype("float32"), (4, 47, 53))
+    out["small_resized_b"] = resize(small[:, :1, :2].astype("float32"), (4, 9, 11))
+    # whole function
+    st = synthetic.make_stack(10, 90, 110, seed=13)
+    out["g_stack"] = st
+    for tag, kw in [("avg10", dict(method="max_averages", bin_size=10)), ("std4", dict(method="max_std", bin_size=4)),
+                    ("multi10", dict(method="multi_channel", bin_size=10)),
+                    ("avg7_shift", dict(method="max_averages", bin_size=7, atoh_shift=1))]:
+        proj, zmap = sp.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, z_map=True, **kw)
+        out["g_%s_proj" % tag] = proj
+        out["g_%s_zmap" % tag] = zmap
+    st3 = synthetic.make_stack(8, 64, 96, seed=14, channels=3, offset=10000)
+    out["h_stack"] = st3
+    proj, zmap = sp.time_point_surface_projection(st3.copy(), "CZYX", 2, airyscan=True, z_map=True, method="multi_channel",
+                                                  bin_size=16)
+    out["h_multi16_proj"] = proj
+    out["h_multi16_zmap"] = zmap
+    try:
+        sp.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, method="nope", bin_size=2)
+        err = "none"
+    except Exception as e:
+        err = type(e).__name__
+    out["bad_method_error"] = np.array(err)
+    save("projection_binned", **out)
+
+
 def gold_rank_filters():
     rng = np.random.default_rng(21)
     lab = rng.integers(0, 40, (37, 53)).astype(np.int32)
@@ -474,6 +514,7 @@ if __name__ == "__main__":
     gold_gaussian()
     gold_percentile()
     pa, pf = gold_projection()
+    gold_projection_binned()
     gold_rank_filters()
     gold_label()
     la, lb = gold_watershed(pa, pf)
