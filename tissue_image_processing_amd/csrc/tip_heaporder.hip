@@ -39,8 +39,9 @@ struct Bits {
 
 }  // namespace
 
-// c[i]: entries pushed when marker i (raster rank i among the markers) pops.  E[i] = its position in the pop order.
-int marker_pop_order(const uint8_t *c, long M, uint32_t *E)
+// c[i]: entries pushed when marker i (raster rank i among the markers) pops.  order[t] = the marker popped t-th (written
+// front to back: the inverse permutation, which the flood needs, is a scatter the device does better than the host).
+int marker_pop_order(const uint8_t *c, long M, uint32_t *order)
 {
     if (M <= 0) return TIP_OK;
     Bits in_crown(M, true), taken(M, false);   // position still holds a marker / marker already emitted or sitting at the root
@@ -68,7 +69,7 @@ int marker_pop_order(const uint8_t *c, long M, uint32_t *E)
     uint32_t t = 0;
     taken.set(0);
     for (;;) {
-        E[root] = t++;
+        order[t++] = (uint32_t)root;
         const long last = n - 1;
         n -= 1;
         if (n == 0) break;
@@ -122,5 +123,9 @@ int marker_pop_order(const uint8_t *c, long M, uint32_t *E)
 extern "C" __attribute__((visibility("default"))) int tip_marker_pop_order_host(const uint8_t *c, long m, uint32_t *e)
 {
     if (!c || !e || m < 0) return tip::fail(TIP_ERR_ARG, "tip_marker_pop_order_host: bad arguments");
-    return tip::marker_pop_order(c, m, e);
+    std::vector<uint32_t> order((size_t)m);
+    int rc = tip::marker_pop_order(c, m, order.data());
+    if (rc) return rc;
+    for (long t = 0; t < m; ++t) e[order[(size_t)t]] = (uint32_t)t;
+    return TIP_OK;
 }

@@ -25,7 +25,7 @@
 namespace tip {
 
 int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
-int marker_pop_order(const uint8_t *c, long M, uint32_t *E);   // tip_heaporder.hip
+int marker_pop_order(const uint8_t *c, long M, uint32_t *order);   // tip_heaporder.hip
 
 // ---- helpers ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long enc_f64(double d)
@@ -780,6 +780,13 @@ __global__ void __launch_bounds__(256) k_mb_push_counts(const unsigned long long
     c[mrank[i]] = (unsigned char)k;
 }
 
+// E[order[t]] = t: pop rank of every marker from the pop sequence
+__global__ void __launch_bounds__(256) k_mb_invert(const unsigned *__restrict__ order, unsigned *__restrict__ E, long M)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) E[order[t]] = (unsigned)t;
+}
+
 __global__ void __launch_bounds__(256) k_mb_init(unsigned long long *__restrict__ st, const int *__restrict__ mrank,
                                                  const unsigned *__restrict__ E, unsigned long long *__restrict__ cand, long n)
 {
@@ -948,11 +955,11 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         TIP_HIP(hipMemcpyAsync(&M, total_d, sizeof(int), hipMemcpyDeviceToHost, s));
         TIP_HIP(hipStreamSynchronize(s));
         unsigned char *c_d = ws.get<unsigned char>((size_t)M);
-        unsigned *E_d = ws.get<unsigned>((size_t)M);
+        unsigned *E_d = ws.get<unsigned>((size_t)M), *order_d = ws.get<unsigned>((size_t)M);
         unsigned long long *cand = ws.get<unsigned long long>(n);
         int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1);
         int *kflag = ws.get<int>((size_t)4 * M + 4), *drank = ws.get<int>((size_t)4 * M + 4);
-        if (!c_d || !E_d || !cand || !lists || !counter || !kflag || !drank) return TIP_ERR_NOMEM;
+        if (!c_d || !E_d || !order_d || !cand || !lists || !counter || !kflag || !drank) return TIP_ERR_NOMEM;
         TIP_LAUNCH("mb_push_counts", k_mb_push_counts, dim3(cdiv(X, 256), Y), dim3(256), 0, (const unsigned long long *)st,
                    (const int *)mrank, c_d, Y, X);
         {
@@ -961,9 +968,10 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_HIP(hipMemcpyAsync(hc.data(), c_d, (size_t)M, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
             if ((rc = marker_pop_order(hc.data(), M, hE.data()))) return rc;
-            TIP_HIP(hipMemcpyAsync(E_d, hE.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
+            TIP_HIP(hipMemcpyAsync(order_d, hE.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
             TIP_HIP(hipStreamSynchronize(s));   // hE goes out of scope
         }
+        TIP_LAUNCH("mb_invert", k_mb_invert, dim3(cdiv(M, 256)), dim3(256), 0, (const unsigned *)order_d, E_d, (long)M);
         TIP_LAUNCH("mb_init", k_mb_init, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)mrank, (const unsigned *)E_d, cand, n);
         // (b) generations
         int *cur_list = lists, *next_list = lists + n;     // next_list doubles as the unordered append buffer: the ranked

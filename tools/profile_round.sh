@@ -1,24 +1,31 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence for profiles/ into gpurun_out/prof/.
-#   kernel stats with one frame in flight and with the default command, then FETCH_SIZE / WRITE_SIZE in separate passes
+#   classical leg: kernel stats with one frame in flight and with the default command (which also times the U-Net leg),
+#   FETCH_SIZE / WRITE_SIZE in separate passes; U-Net leg: kernel stats and an MFMA-busy counter pass.
 set -o pipefail
-tag=${1:-r01x}
+tag=${1:-r02x}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/s1 -o s1 -- python3 bench.py --inflight 1 --no-cpu-baseline > $out/${tag}_bench_inflight1_profiled.json 2> $out/s1.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/s1 -o s1 -- python3 bench.py --inflight 1 --no-cpu-baseline --no-unet-leg > $out/${tag}_bench_inflight1_profiled.json 2> $out/s1.err || exit 1
 echo "stats inflight 1 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -o s3 -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_default_profiled.json 2> $out/s3.err || exit 1
 echo "stats default done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/pf.json 2> $out/pf.err || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-unet-leg > $out/pf.json 2> $out/pf.err || exit 1
 echo "pmc fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/pw.json 2> $out/pw.err || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-unet-leg > $out/pw.json 2> $out/pw.err || exit 1
 echo "pmc write done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/su -o su -- python3 bench.py --workload unet --steps 3 --warmup 2 --no-cpu-baseline > $out/${tag}_bench_unet_profiled.json 2> $out/su.err || exit 1
+echo "stats unet done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pm -o pm -- python3 bench.py --workload unet --steps 1 --warmup 1 --no-cpu-baseline > $out/pm.json 2> $out/pm.err || exit 1
+echo "pmc mfma done"
 cp $(find $out/s1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_inflight1.csv
-cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_default_inflight3.csv
+cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_default_inflight4.csv
+cp $(find $out/su -name "*kernel_stats.csv" | head -1) $out/${tag}_unet_kernel_stats.csv
 f=$(find $out/pf -name "*counter_collection.csv" | head -1); w=$(find $out/pw -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $f $w $out/${tag}_pmc_traffic.json
-python3 - "$f" "$out/${tag}_pmc_fetch_size.csv" <<'PY'
+for pair in "$f:$out/${tag}_pmc_fetch_size.csv" "$w:$out/${tag}_pmc_write_size.csv"; do
+python3 - "${pair%%:*}" "${pair##*:}" <<'PY'
 import sys, csv
 # keep the per-dispatch counter rows of our kernels only (the raw file also lists every runtime fill/copy)
 rows = [r for r in csv.reader(open(sys.argv[1]))]
@@ -27,13 +34,24 @@ ki = hdr.index("Kernel_Name")
 keep = [r for r in body if not r[ki].startswith("__amd")]
 csv.writer(open(sys.argv[2], "w")).writerows([hdr] + keep)
 PY
-python3 - "$w" "$out/${tag}_pmc_write_size.csv" <<'PY'
-import sys, csv
-rows = [r for r in csv.reader(open(sys.argv[1]))]
-hdr, body = rows[0], rows[1:]
-ki = hdr.index("Kernel_Name")
-keep = [r for r in body if not r[ki].startswith("__amd")]
-csv.writer(open(sys.argv[2], "w")).writerows([hdr] + keep)
+done
+# MFMA utilisation of the U-Net's kernels: busy cycles of the matrix pipe / busy CU cycles, per kernel (summed over launches)
+python3 - "$(find $out/pm -name '*counter_collection.csv' | head -1)" "$out/${tag}_unet_mfma_busy.json" <<'PY'
+import sys, csv, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); calls = collections.defaultdict(int)
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"].split("(")[0][:100]
+    acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_BUSY_CU_CYCLES":
+        dur[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); calls[n] += 1
+out = {}
+for n in sorted(acc, key=lambda k: -dur[k])[:25]:
+    a = acc[n]
+    busy = a.get("SQ_BUSY_CU_CYCLES", 0.0)
+    out[n] = {"calls": calls[n], "total_ms": round(dur[n] / 1e6, 3), "SQ_VALU_MFMA_BUSY_CYCLES": a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
+              "SQ_BUSY_CU_CYCLES": busy, "mfma_busy_over_cu_busy": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy, 4) if busy else None}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print("wrote", sys.argv[2])
 PY
-rm -rf $out/s1 $out/s3 $out/pf $out/pw
+rm -rf $out/s1 $out/s3 $out/pf $out/pw $out/su $out/pm
 ls -la $out
