@@ -120,8 +120,9 @@ def test_config5_frame_4096x4096x60():
     assert n == tabs["area"].size and n > 10000
     np.testing.assert_array_equal(np.bincount(lab.ravel(), minlength=n + 1)[1:], tabs["area"])
     assert int((lab == 0).sum()) + int(tabs["area"].sum()) == N * N
-    # a crop of the projection through the oracle's watershed_segmentation == the device result on the same crop
+    # a crop of the projection through the oracle's watershed_segmentation == the device result on the same crop (a crop
+    # inside one mirror image: across a mirror line the landscape has exact value ties between non-marker pixels)
     from tissue_image_processing_amd import _segmentation as seg
-    crop = np.ascontiguousarray(proj[0][1500:2100, 900:1700])
+    crop = np.ascontiguousarray(proj[0][1100:1700, 1200:1900])
     np.testing.assert_array_equal(seg.watershed_segmentation(crop, 0.03, 3, 3), orc.watershed_segmentation(crop, 0.03, 3, 3))
     d.free()
