@@ -100,6 +100,16 @@ TIP_API int tip_project_u16_binned_dev(const uint16_t *czyx, int c, int z, int y
                                        int ref_ch, int method, int bin_size, int airyscan, int atoh_shift,
                                        const double *t05, const double *t1, const double *t2, const double *t30,
                                        double *proj, int64_t *zmap);
+/* Spatial tiles of one frame (BASELINE config 5; tiling.py): the 95th percentile of sp.py:33-36 is a property of the */
+/* WHOLE reference channel, so tiles first add up 65536-bin histograms of their interiors (tip_hist_u16_box_dev adds   */
+/* the box [z0,z1) x [y0,y1) x [x0,x1) of channel ch into hist_dev, uint64 counts of the offset-corrected values), and */
+/* every tile (+ halo) is then projected with the frame's histogram instead of its own.                               */
+TIP_API int tip_hist_u16_box_dev(const uint16_t *czyx, int c, int z, int y, int x, int ch, int z0, int z1, int y0, int y1,
+                                 int x0, int x1, int airyscan, unsigned long long *hist_dev);
+TIP_API int tip_project_u16_hist_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z,
+                                     int ref_ch, int airyscan, int atoh_shift,
+                                     const double *t05, const double *t1, const double *t2, const double *t30,
+                                     const unsigned long long *hist_dev, double *proj, int64_t *zmap);
 
 /* ---- rank filters ---------------------------------------------------------------------------- */
 /* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */

@@ -236,8 +236,9 @@ def resize_linear(a, out_yx):
 
 def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, max_z=0,
                                   method="max_averages", bin_size=1, airyscan=True, z_map=False,
-                                  atoh_shift=0, build_manifold=False):
-    """sp.py:17-85 (build_manifold False)."""
+                                  atoh_shift=0, build_manifold=False, clip_from=None):
+    """sp.py:17-85 (build_manifold False).  clip_from (not in the reference): the array whose non-zero 95th percentile
+    clips the reference channel instead of the channel's own -- a spatial tile passes the whole frame's channel."""
     if build_manifold:
         raise NotImplementedError("oracle: build_manifold=False")
     if axes.find("T") >= 0:
@@ -252,7 +253,8 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
     if max_z > 0:
         image = image[:, min_z:max_z, :, :]
     ch = np.copy(image[reference_channel])
-    nz = ch[ch > 0]
+    src = ch if clip_from is None else np.asarray(clip_from, np.float32)
+    nz = src[src > 0]
     if nz.size > 0:
         p95 = percentile_linear(nz, 95)
         # numpy 1.x value-based casting: the float64 scalar is compared/assigned as float32

@@ -126,3 +126,20 @@ def test_config5_frame_4096x4096x60():
     crop = np.ascontiguousarray(proj[0][1100:1700, 1200:1900])
     np.testing.assert_array_equal(seg.watershed_segmentation(crop, 0.03, 3, 3), orc.watershed_segmentation(crop, 0.03, 3, 3))
     d.free()
+
+
+@pytest.mark.parametrize("shape,grid", [((8, 700, 900), (2, 3)), ((5, 300, 1100), (1, 4)), ((6, 512, 512), (2, 2))])
+def test_tiled_projection_equals_untiled(shape, grid):
+    """Config 5's spatial tiling (tiling.py): tiles + 132-pixel halo + the frame's summed percentile histogram give the
+    untiled projection and z-map bit for bit (one process walks all tiles here; the 2-rank exchange is the gloo test)."""
+    from tissue_image_processing_amd import synthetic, tiling, surface_projection as sp
+    Z, Y, X = shape
+    st = synthetic.make_stack(Z, Y, X, seed=91)
+    proj, zmap = sp.time_point_surface_projection(st, "CZYX", 0, airyscan=False, z_map=True)
+    backend = tiling.GpuTileBackend(reference_channel=0, airyscan=False)
+    tp, tz = tiling.project_tiled(lambda a, b, c, d: st[:, :, a:b, c:d], 2, Y, X, grid, backend)
+    assert int((tz != zmap).sum()) == 0
+    np.testing.assert_array_equal(tp, proj)
+    p3, z3, lab = tiling.process_tiled_frame(lambda a, b, c, d: st[:, :, a:b, c:d], 2, Y, X, grid, backend)
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    np.testing.assert_array_equal(lab, bim.watershed_segmentation(proj[0], 0.03, 3, 3))

@@ -65,6 +65,34 @@ __global__ void __launch_bounds__(1024) k_hist_u16(const uint16_t *__restrict__ 
     }
 }
 
+// The same histogram over a sub-box [z0,z1) x [y0,y1) x [x0,x1) of one channel plane stack (row length X, plane size
+// Y*X): spatially tiled frames (config 5) count every voxel once -- tile interiors -- and add the tiles' histograms up
+// before anyone clips (the percentile is a property of the whole frame).
+__global__ void __launch_bounds__(1024) k_hist_u16_box(const uint16_t *__restrict__ in, int Y, int X, int z0, int y0, int x0, int bz,
+                                                       int by, int bx, int airy, unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned int h[32768];
+    for (int i = threadIdx.x; i < 32768; i += 1024) h[i] = 0;
+    __syncthreads();
+    const long n = (long)bz * by * bx;
+    const long base = (long)blockIdx.x * HIST_PER_BLOCK;
+    for (int k = 0; k < HIST_PER_BLOCK / 1024; ++k) {
+        const long i = base + (long)k * 1024 + threadIdx.x;
+        if (i < n) {
+            const int x = (int)(i % bx), y = (int)((i / bx) % by), z = (int)(i / ((long)bx * by));
+            int val = in[((long)(z0 + z) * Y + (y0 + y)) * X + (x0 + x)];
+            if (airy) { val -= 10000; if (val < 0) val = 0; }
+            atomicAdd(&h[val >> 1], 1u << (16 * (val & 1)));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32768; i += 1024) {
+        const unsigned int c = h[i];
+        if (c & 0xffffu) atomicAdd(&hist[2 * i], (unsigned long long)(c & 0xffffu));
+        if (c >> 16) atomicAdd(&hist[2 * i + 1], (unsigned long long)(c >> 16));
+    }
+}
+
 // np.percentile(nonzero, 95) with numpy 1.26 arithmetic (see oracle.percentile_linear): one block.
 // (with_zero: over all voxels, zeros included -- the second channel of method 'multi_channel', sp.py:46)
 __global__ void __launch_bounds__(1024) k_percentile95(const unsigned long long *__restrict__ hist, ClipInfo *out, int with_zero)
@@ -656,7 +684,7 @@ static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
 
 int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int zhi, int min_z, int ref_ch, int method, int bin,
                 int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
-                const double *t30, double *proj, int64_t *zmap)
+                const double *t30, double *proj, int64_t *zmap, const unsigned long long *hist_in = nullptr)
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
@@ -685,10 +713,15 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     if (!A || !B || !hist || !clip || !zsel || !zsel_a || !ident || !table || !err) return TIP_ERR_NOMEM;
 
     const uint16_t *ref = czyx + ((long)ref_ch * Z + zlo) * P;
-    TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
     TIP_HIP(hipMemsetAsync(err, 0, sizeof(int), c.stream));
-    TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, ref, V, airyscan, hist);
-    TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip, 0);
+    if (hist_in) {   // a tile of a larger frame: the caller brings the whole frame's histogram
+        if (bin > 1 && method == 2) return fail(TIP_ERR_UNSUPPORTED, "project: tiles with method multi_channel");
+        TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist_in, clip, 0);
+    } else {
+        TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
+        TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, ref, V, airyscan, hist);
+        TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, (const unsigned long long *)hist, clip, 0);
+    }
 
     const bool fast = (X % 4 == 0) && !getenv("TIP_PROJECT_GENERIC");
     // P3: (0.5, 1, 1) of the clipped channel -> A_, then P4's z pass (0.5) of that -> B_
@@ -733,7 +766,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                 if (!S2 || !clip2) return TIP_ERR_NOMEM;
                 TIP_HIP(hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), c.stream));
                 TIP_LAUNCH("hist_u16", k_hist_u16, dim3(cdiv(V, HIST_PER_BLOCK)), dim3(1024), 0, other, V, airyscan, hist);
-                TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, hist, clip2, 1);
+                TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, (const unsigned long long *)hist, clip2, 1);
                 if ((rc = short_blur(other, clip2, A, B))) return rc;
                 if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
                 if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
@@ -862,6 +895,29 @@ int tip_project_u16(const uint16_t *czyx, int c, int z, int y, int x, int zlo, i
                     const double *t30, double *proj, int64_t *zmap)
 {
     return project_host(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, 0, 1, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+int tip_hist_u16_box_dev(const uint16_t *czyx, int c, int z, int y, int x, int ch, int z0, int z1, int y0, int y1, int x0, int x1,
+                         int airyscan, unsigned long long *hist_dev)
+{
+    Ctx &cx = ctx();
+    if (!cx.stream) return TIP_ERR_HIP;
+    if (!czyx || !hist_dev) return fail(TIP_ERR_ARG, "tip_hist_u16_box_dev: null pointer");
+    if (ch < 0 || ch >= c || z0 < 0 || z1 > z || z1 <= z0 || y0 < 0 || y1 > y || y1 <= y0 || x0 < 0 || x1 > x || x1 <= x0)
+        return fail(TIP_ERR_ARG, "tip_hist_u16_box_dev: box outside the (%d,%d,%d,%d) stack", c, z, y, x);
+    const long n = (long)(z1 - z0) * (y1 - y0) * (x1 - x0);
+    const uint16_t *plane = czyx + (long)ch * z * y * x;
+    TIP_LAUNCH("hist_u16_box", k_hist_u16_box, dim3(cdiv(n, HIST_PER_BLOCK)), dim3(1024), 0, plane, y, x, z0, y0, x0, z1 - z0, y1 - y0,
+               x1 - x0, airyscan, hist_dev);
+    return TIP_OK;
+}
+
+int tip_project_u16_hist_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,
+                             int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
+                             const double *t30, const unsigned long long *hist_dev, double *proj, int64_t *zmap)
+{
+    if (!hist_dev) return fail(TIP_ERR_ARG, "tip_project_u16_hist_dev: null histogram");
+    return project_dev(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, 0, 1, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap, hist_dev);
 }
 
 int tip_project_u16_binned_dev(const uint16_t *czyx, int c, int z, int y, int x, int zlo, int zhi, int min_z, int ref_ch,

@@ -20,6 +20,7 @@
 // breadth-first search in generations whose pixels carry dense ranks (see the mode B section below).
 #include "tip_internal.h"
 #include "tip_uf.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace tip {
@@ -799,21 +800,38 @@ __global__ void __launch_bounds__(256) k_mb_init(unsigned long long *__restrict_
 
 // a labelled pixel p of rank r pushes its undecided neighbours: key = r * 4 + slot, slot = position of the neighbour in
 // skimage's push order (up, left, right, down).  The first push of a pixel appends it to the next generation's list.
-__device__ __forceinline__ void mb_push_from(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
-                                             int *__restrict__ next, int *__restrict__ counter, int p, int Y, int X)
+// append `value` to list[] for every lane with pred set: one atomic per wave instead of one per lane (hundreds of
+// thousands of same-address atomics serialise in L2)
+__device__ __forceinline__ void wave_append(bool pred, int value, int *__restrict__ list, int *__restrict__ counter)
 {
-    const unsigned long long s = st[p];
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ULL) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (pred) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = value;
+}
+
+__device__ __forceinline__ void mb_push_from(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
+                                             int *__restrict__ next, int *__restrict__ counter, int p, bool active, int Y, int X)
+{
+    // (all 64 lanes walk the four slots together -- the appends are wave-wide -- inactive lanes push nothing)
+    const unsigned long long s = active ? st[p] : 0ULL;
     const int l = st_lab(s);
-    if (l <= 0) return;
+    active = active && l > 0;
     const unsigned long long r4 = (unsigned long long)(unsigned)(st_tref(s) - 1) * 4ULL;
-    const int y = p / X, x = p - y * X;
+    const int y = active ? p / X : 0, x = active ? p - y * X : 0;
     const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int u = nb[k];
-        if (u < 0 || st[u] != 0ULL) continue;
-        const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
-        if (atomicMin(&cand[u], val) == MB_NONE) next[atomicAdd(counter, 1)] = u;
+        bool first = false;
+        if (active && u >= 0 && st[u] == 0ULL) {
+            const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
+            first = atomicMin(&cand[u], val) == MB_NONE;
+        }
+        wave_append(first, u, next, counter);
     }
 }
 
@@ -821,7 +839,7 @@ __global__ void __launch_bounds__(256) k_mb_push_markers(unsigned long long *__r
                                                          int *__restrict__ next, int *__restrict__ counter, int Y, int X)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x < X) mb_push_from(st, cand, next, counter, y * X + x, Y, X);
+    mb_push_from(st, cand, next, counter, y * X + min(x, X - 1), x < X, Y, X);
 }
 
 __global__ void __launch_bounds__(256) k_mb_push_list(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
@@ -829,7 +847,7 @@ __global__ void __launch_bounds__(256) k_mb_push_list(unsigned long long *__rest
                                                       int *__restrict__ counter, int Y, int X)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nlist) mb_push_from(st, cand, next, counter, list[i], Y, X);
+    mb_push_from(st, cand, next, counter, i < nlist ? list[i] : 0, i < nlist, Y, X);
 }
 
 __global__ void __launch_bounds__(256) k_mb_flag_keys(const unsigned long long *__restrict__ cand, const int *__restrict__ next,
@@ -851,41 +869,70 @@ __global__ void __launch_bounds__(256) k_mb_assign_ranks(unsigned long long *__r
     list[r] = u;
 }
 
-// fate of the generation's pixels, in rank order: a pixel waits while a same-generation neighbour of smaller rank is
-// still pending (its fate decides whether this pixel sees a second label)
-__global__ void __launch_bounds__(256) k_mb_resolve(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                    const int *__restrict__ list, int nlist, int Y, int X, WsInfo *info)
+// fate of one pixel of the generation (rank r): true when decided.  A pixel waits while a same-generation neighbour of
+// smaller rank is still pending (its fate decides whether this pixel sees a second label).
+__device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst, const unsigned long long *__restrict__ cand, int p,
+                                               int myr, int Y, int X)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nlist) return;
-    const int p = list[i];
-    volatile unsigned long long *vst = st;
-    if (st_lab(vst[p]) != 0) return;
-    const int myr = i + 1;
     const int y = p / X, x = p - y * X;
     const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        int l0 = 0;
-        bool diff = false, pending = false;
+    int l0 = 0;
+    bool diff = false, pending = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (nb[k] < 0) continue;
-            const unsigned long long s = vst[nb[k]];
-            const int l = st_lab(s);
-            if (l > 0) {
-                if (l0 == 0) l0 = l;
-                else if (l != l0) diff = true;
-            } else if (l == 0) {
-                const int r = st_tref(s);
-                pending |= r != 0 && r < myr;
-            }
-        }
-        if (!pending) {
-            vst[p] = pack_st(diff ? LINE_LAB : (int)(unsigned)(cand[p] & 0xffffffffULL), myr);
-            return;
+    for (int k = 0; k < 4; ++k) {
+        if (nb[k] < 0) continue;
+        const unsigned long long s = vst[nb[k]];
+        const int l = st_lab(s);
+        if (l > 0) {
+            if (l0 == 0) l0 = l;
+            else if (l != l0) diff = true;
+        } else if (l == 0) {
+            const int r = st_tref(s);
+            pending |= r != 0 && r < myr;
         }
     }
-    atomicAdd(&info->undecided, 1);   // (rare: only pixels behind a chain of same-generation neighbours get here)
+    if (pending) return false;
+    vst[p] = pack_st(diff ? LINE_LAB : (int)(unsigned)(cand[p] & 0xffffffffULL), myr);
+    return true;
+}
+
+// first pass, all pixels of the generation in parallel; the ones left waiting (chains of adjacent same-generation pixels
+// along collision fronts) are listed for the tail
+__global__ void __launch_bounds__(256) k_mb_resolve(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                    const int *__restrict__ list, int nlist, int Y, int X, int *__restrict__ pend,
+                                                    int *__restrict__ npend)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool waiting = false;
+    if (i < nlist) {
+        const int p = list[i];
+        waiting = true;
+        for (int attempt = 0; attempt < 4 && waiting; ++attempt) waiting = !mb_try_resolve(st, cand, p, i + 1, Y, X);
+    }
+    wave_append(waiting, i, pend, npend);
+}
+
+// tail: ONE block sweeps the waiting pixels until all are decided (every sweep decides at least the smallest-ranked
+// one, so at most n sweeps; chains are a few dozen pixels long).  One block: no host round trip per sweep, and the
+// block's own stores are visible to its (volatile) loads after the barrier.
+__global__ void __launch_bounds__(1024) k_mb_resolve_tail(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                          const int *__restrict__ list, const int *__restrict__ pend,
+                                                          const int *__restrict__ npend, int Y, int X, WsInfo *info)
+{
+    const int n = *npend;
+    volatile unsigned long long *vst = st;
+    int left = n;
+    for (int sweep = 0; sweep <= n && left > 0; ++sweep) {
+        int mine = 0;
+        for (int j = threadIdx.x; j < n; j += 1024) {
+            const int i = pend[j], p = list[i];
+            if (st_lab(vst[p]) != 0) continue;
+            if (!mb_try_resolve(vst, cand, p, i + 1, Y, X)) mine = 1;
+        }
+        __threadfence_block();
+        left = __syncthreads_count(mine);
+    }
+    if (threadIdx.x == 0 && left) info->unfinished = 1;   // only if the generation is inconsistent (never seen)
 }
 
 __global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__restrict__ st, int32_t *__restrict__ out, long n)
@@ -957,8 +1004,11 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         unsigned char *c_d = ws.get<unsigned char>((size_t)M);
         unsigned *E_d = ws.get<unsigned>((size_t)M), *order_d = ws.get<unsigned>((size_t)M);
         unsigned long long *cand = ws.get<unsigned long long>(n);
-        int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1);
-        int *kflag = ws.get<int>((size_t)4 * M + 4), *drank = ws.get<int>((size_t)4 * M + 4);
+        int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1), *pend = isroot;   // (isroot is free here)
+        // rank keys of a generation live in [0, 4 * size of the previous one): the markers first, later at most every
+        // other pixel
+        const size_t keycap = (size_t)4 * (size_t)std::max<long>(M, n - M) + 4;
+        int *kflag = ws.get<int>(keycap), *drank = ws.get<int>(keycap);
         if (!c_d || !E_d || !order_d || !cand || !lists || !counter || !kflag || !drank) return TIP_ERR_NOMEM;
         TIP_LAUNCH("mb_push_counts", k_mb_push_counts, dim3(cdiv(X, 256), Y), dim3(256), 0, (const unsigned long long *)st,
                    (const int *)mrank, c_d, Y, X);
@@ -995,21 +1045,18 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             if ((rc = exclusive_scan_i32(kflag, drank, keyspace, nullptr))) return rc;
             TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
                        (const int *)unordered, nnext, (const int *)drank, next_list);
-            for (int pass = 0, waiting = nnext + 1;; ++pass) {
-                TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-                TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
-                           (const int *)next_list, nnext, Y, X, info);
-                TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
-                TIP_HIP(hipStreamSynchronize(s));
-                if (h.undecided == 0) break;
-                // the smallest-ranked waiting pixel has no pending neighbour of smaller rank, so every pass decides some
-                if (h.undecided >= waiting) return fail(TIP_ERR_HIP, "watershed: generation %d made no progress", gen);
-                waiting = h.undecided;
-            }
+            TIP_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));      // (nnext was read: the counter now counts waiting pixels)
+            TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
+                       (const int *)next_list, nnext, Y, X, pend, counter);
+            TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
+                       (const int *)next_list, (const int *)pend, (const int *)counter, Y, X, info);
             std::swap(cur_list, next_list);
             ncur = nnext;
             keyspace = 4L * nnext;
         }
+        TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
+        TIP_HIP(hipStreamSynchronize(s));
+        if (h.unfinished != 0) return fail(TIP_ERR_HIP, "watershed: a generation of the two-valued flood did not resolve");
     } else if (h.n_markers > 0) {
         const int tilesX = cdiv(X, WT_FAST), tilesY = cdiv(Y, WT_FAST), ntiles = tilesX * tilesY;
         const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
