@@ -160,6 +160,12 @@ TIP_API int tip_regionprops_i32_dev(const int32_t *labels, const double *intensi
 TIP_API int tip_neighbor_pairs_i32(const int32_t *labels, int y, int x, int32_t *pairs, int64_t cap, int64_t *n_pairs);
 TIP_API int tip_neighbor_pairs_i32_dev(const int32_t *labels, int y, int x, int32_t *pairs_dev, int64_t cap,
                                        int64_t *n_pairs_host);
+/* Contact lengths (ti.py:1844-1872, 4073-4094): for every ordered label pair (hi > lo >= 1) the number of pixels whose  */
+/* 4-neighbour maximum of the labels is hi and whose 4-neighbour minimum of the labels with zeros replaced by `big`    */
+/* (= max label + 1, ti.py:4081) is lo; filters as scipy's with the cross footprint and mode='constant'.  pairs: (hi, */
+/* lo) rows, counts: the pixel numbers, in no particular order.                                                        */
+TIP_API int tip_contact_pairs_i32(const int32_t *labels, int y, int x, int big, int32_t *pairs, int64_t *counts, int64_t cap,
+                                  int64_t *n_pairs);
 /* Tissue.update_labels (ti.py:2967-2970): negatives take the zero-padded 3x3 maximum              */
 TIP_API int tip_update_labels_i32(int32_t *labels, int y, int x);
 /* track_cells_iterator's label lookup (ti.py:2081-2090): maximum_filter(labels,(3,3),'constant') sampled at query   */

@@ -265,6 +265,26 @@ def test_cellinfo_golden(env, golden, tag):
     np.testing.assert_array_equal(t.calc_neighbors_contact_matrix(1), g[tag + "_contact"])
 
 
+def test_contact_matrix_vs_oracle_synthetic_frame(env):
+    """C6 on a few hundred cells: the device pair histogram (tip_contact_pairs_i32) against the reference's per-cell,
+    per-neighbour counting inside bounding boxes (oracle), including labels that do not occur and cells at the border."""
+    bim, seg, ti, orc = env
+    rng = np.random.default_rng(8)
+    land = orc.blur_image(rng.random((300, 420)), 4.0)
+    lab = orc.watershed(land)
+    lab[lab == 7] = 0                      # a label that does not occur any more
+    lab[120:130, 200:260] = 0              # a thick line: neighbours (5x5 rule) that do not touch (cross rule)
+    t = ti.Tissue(1)
+    t.set_labels(1, lab.copy(), reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    t.find_neighbors(1)
+    ci = t.get_cells_info(1)
+    want = orc.contact_matrix(lab, list(ci.neighbors))
+    got = t.calc_neighbors_contact_matrix(1)
+    np.testing.assert_array_equal(got, want)
+    assert got.sum() > 1000
+
+
 def test_update_labels_golden(env, golden):
     _, _, ti, _ = env
     g = golden("cellinfo")

@@ -168,3 +168,26 @@ def neighbor_pairs(labels, cap=None):
     if p.size:
         p = p[np.lexsort((p[:, 1], p[:, 0]))]
     return p
+
+
+def contact_pairs(labels, cap=None):
+    """{(hi, lo): pixels} for the contact-length rule of ti.py:1844-1872: pixels whose cross-footprint maximum of the labels
+    is hi and whose cross-footprint minimum (zeros replaced by max + 1) is lo, hi > lo >= 1.  One device pass."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    big = int(labels.max()) + 1
+    grow = cap is None
+    if cap is None:
+        cap = max(4096, 16 * big)
+    while True:
+        pairs = np.empty((cap, 2), np.int32)
+        counts = np.empty(cap, np.int64)
+        n = ctypes.c_int64(0)
+        rc = _lib.lib().tip_contact_pairs_i32(_lib.ptr(labels), labels.shape[0], labels.shape[1], big, _lib.ptr(pairs),
+                                              _lib.ptr(counts), ctypes.c_int64(cap), ctypes.byref(n))
+        if rc == _lib.TIP_ERR_OVERFLOW and grow and cap < 8 * labels.size:
+            cap *= 8
+            continue
+        _lib.check(rc)
+        break
+    k = int(n.value)
+    return {(int(h), int(l)): int(c) for (h, l), c in zip(pairs[:k].tolist(), counts[:k].tolist())}

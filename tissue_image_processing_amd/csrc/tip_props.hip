@@ -325,6 +325,96 @@ int neighbor_pairs_dev(const int32_t *labels, int Y, int X, int32_t *pairs_dev, 
     return TIP_OK;
 }
 
+// ---- contact lengths (ti.py:1844-1872, 4073-4094): histogram of (cross max, cross min) label pairs -----------------
+// The reference counts, per cell and neighbour, the pixels of the cell's bounding box (+2) whose 4-neighbour maximum of
+// the labels is the larger and whose 4-neighbour minimum of the labels (zeros replaced by max+1) is the smaller of the two
+// labels (scipy maximum_filter / minimum_filter with the cross footprint, mode='constant').  Such a pixel touches both
+// cells, so it always lies inside that box: the per-pair number is a property of the label map -- one pass, one hash
+// histogram keyed (hi << 32 | lo).
+__device__ __forceinline__ long np_slot(unsigned long long key, unsigned long long *__restrict__ table, unsigned long long tmask)
+{
+    unsigned long long h = mix64(key) & tmask;
+    for (unsigned long long probes = 0; probes <= tmask; ++probes) {
+        const unsigned long long cur = table[h];
+        if (cur == key) return (long)h;
+        if (cur == 0ULL) {
+            const unsigned long long old = atomicCAS(&table[h], 0ULL, key);
+            if (old == 0ULL || old == key) return (long)h;
+        }
+        h = (h + 1) & tmask;
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) k_contact_pairs(const int32_t *__restrict__ lab, int Y, int X, int big,
+                                                       unsigned long long *__restrict__ table, unsigned long long *__restrict__ counts,
+                                                       unsigned long long tmask, int *__restrict__ overflow)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const long i = (long)y * X + x;
+    const int nb[4] = {y > 0 ? lab[i - X] : -1, x > 0 ? lab[i - 1] : -1, x < X - 1 ? lab[i + 1] : -1, y < Y - 1 ? lab[i + X] : -1};
+    int mx = 0, mn = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = nb[k];                      // -1: outside the image = the filters' constant 0
+        mx = max(mx, v < 0 ? 0 : v);
+        mn = min(mn, v < 0 ? 0 : (v == 0 ? big : v));
+    }
+    if (mx == mn || mn == 0 || mx == 0) return;   // never asked for: a pair is (larger label, smaller label >= 1)
+    const long slot = np_slot(((unsigned long long)(unsigned)mx << 32) | (unsigned)mn, table, tmask);
+    if (slot < 0) { atomicOr(overflow, 1); return; }
+    atomicAdd(&counts[slot], 1ULL);
+}
+
+__global__ void __launch_bounds__(256) k_contact_emit(const unsigned long long *__restrict__ table, const unsigned long long *__restrict__ counts,
+                                                      unsigned long long tsize, int32_t *__restrict__ pairs, int64_t *__restrict__ cnt,
+                                                      long long cap, unsigned long long *__restrict__ n_out)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tsize) return;
+    const unsigned long long key = table[i];
+    if (key == 0ULL) return;
+    const unsigned long long slot = atomicAdd(n_out, 1ULL);
+    if ((long long)slot < cap) {
+        pairs[2 * slot] = (int)(unsigned)(key >> 32);
+        pairs[2 * slot + 1] = (int)(unsigned)key;
+        cnt[slot] = (int64_t)counts[i];
+    }
+}
+
+int contact_pairs_dev(const int32_t *labels, int Y, int X, int big, int32_t *pairs_dev, int64_t *cnt_dev, int64_t cap,
+                      int64_t *n_pairs_host)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!labels || !pairs_dev || !cnt_dev || !n_pairs_host || cap < 1) return fail(TIP_ERR_ARG, "contact_pairs: bad arguments");
+    if (Y < 1 || X < 1 || Y > 65535) return fail(TIP_ERR_ARG, "contact_pairs: bad shape");
+    unsigned long long tsize = 1024;
+    while (tsize < (unsigned long long)cap * 2) tsize <<= 1;
+    WsGuard ws;
+    unsigned long long *table = ws.get<unsigned long long>(tsize), *counts = ws.get<unsigned long long>(tsize),
+                       *n_d = ws.get<unsigned long long>(1);
+    int *ovf = ws.get<int>(1);
+    if (!table || !counts || !n_d || !ovf) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemsetAsync(table, 0, tsize * 8, c.stream));
+    TIP_HIP(hipMemsetAsync(counts, 0, tsize * 8, c.stream));
+    TIP_HIP(hipMemsetAsync(n_d, 0, 8, c.stream));
+    TIP_HIP(hipMemsetAsync(ovf, 0, 4, c.stream));
+    TIP_LAUNCH("contact_pairs", k_contact_pairs, dim3(cdiv(X, 256), Y), dim3(256), 0, labels, Y, X, big, table, counts, tsize - 1, ovf);
+    TIP_LAUNCH("contact_emit", k_contact_emit, dim3(cdiv((long)tsize, 256)), dim3(256), 0, (const unsigned long long *)table,
+               (const unsigned long long *)counts, tsize, pairs_dev, cnt_dev, (long long)cap, n_d);
+    unsigned long long h = 0;
+    int hov = 0;
+    TIP_HIP(hipMemcpyAsync(&h, n_d, 8, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipMemcpyAsync(&hov, ovf, 4, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    *n_pairs_host = (int64_t)h;
+    if (hov || (int64_t)h > cap)
+        return fail(TIP_ERR_OVERFLOW, "contact_pairs: more than %lld distinct label pairs", (long long)cap);
+    return TIP_OK;
+}
+
 }  // namespace tip
 
 using namespace tip;
@@ -384,6 +474,25 @@ int tip_neighbor_pairs_i32(const int32_t *labels, int y, int x, int32_t *pairs, 
     int rc = neighbor_pairs_dev(dl, y, x, dp, cap, n_pairs);
     if (rc) return rc;
     TIP_HIP(hipMemcpyAsync(pairs, dp, (size_t)(*n_pairs) * 8, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+int tip_contact_pairs_i32(const int32_t *labels, int y, int x, int big, int32_t *pairs, int64_t *counts, int64_t cap, int64_t *n_pairs)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!labels || !pairs || !counts || !n_pairs || y < 1 || x < 1 || cap < 1) return fail(TIP_ERR_ARG, "tip_contact_pairs_i32: bad arguments");
+    const size_t P = (size_t)y * x;
+    WsGuard ws;
+    int32_t *dl = ws.get<int32_t>(P), *dp = ws.get<int32_t>((size_t)2 * cap);
+    int64_t *dc = ws.get<int64_t>((size_t)cap);
+    if (!dl || !dp || !dc) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(dl, labels, P * 4, hipMemcpyHostToDevice, c.stream));
+    int rc = contact_pairs_dev(dl, y, x, big, dp, dc, cap, n_pairs);
+    if (rc) return rc;
+    TIP_HIP(hipMemcpyAsync(pairs, dp, (size_t)(*n_pairs) * 8, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipMemcpyAsync(counts, dc, (size_t)(*n_pairs) * 8, hipMemcpyDeviceToHost, c.stream));
     TIP_HIP(hipStreamSynchronize(c.stream));
     return TIP_OK;
 }

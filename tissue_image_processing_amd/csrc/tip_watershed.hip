@@ -140,7 +140,9 @@ __global__ void __launch_bounds__(256) k_ws_lower_flags(const double *__restrict
     if (x < X - 1 && v[i + 1] < h) bad = true;
     if (y < Y - 1 && v[i + X] < h) bad = true;
     if ((y == 0 || x == 0 || y == Y - 1 || x == X - 1) && enc_f64(h) == info->emax) bad = true;
-    if (bad) atomicOr(&flag[parent[i]], 1);
+    // (one giant plateau -- the boundary network of a two-valued image -- would otherwise take hundreds of thousands of
+    // same-address atomics; the flag only ever goes 0 -> 1, so a stale 0 just costs one more atomic)
+    if (bad) { const int r = parent[i]; if (flag[r] == 0) atomicOr(&flag[r], 1); }
 }
 
 __global__ void __launch_bounds__(256) k_ws_min_roots(const int *__restrict__ parent, const int *__restrict__ flag,
@@ -800,54 +802,71 @@ __global__ void __launch_bounds__(256) k_mb_init(unsigned long long *__restrict_
 
 // a labelled pixel p of rank r pushes its undecided neighbours: key = r * 4 + slot, slot = position of the neighbour in
 // skimage's push order (up, left, right, down).  The first push of a pixel appends it to the next generation's list.
-// append `value` to list[] for every lane with pred set: one atomic per wave instead of one per lane (hundreds of
-// thousands of same-address atomics serialise in L2)
-__device__ __forceinline__ void wave_append(bool pred, int value, int *__restrict__ list, int *__restrict__ counter)
+// Block-aggregated append: the items of a 256-thread block are collected in LDS and the block reserves its slice of
+// the global list with ONE atomic (hundreds of thousands of same-address atomics on the list counter serialise in L2:
+// one per lane cost 1.9 ms per frame, one per block costs nothing measurable).
+struct BlockList {
+    int *items;     // LDS, capacity 4 * 256
+    int *count;     // LDS
+    int *base;      // LDS
+};
+__device__ __forceinline__ void bl_init(const BlockList &b)
 {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ULL) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1, 64);
-    if (pred) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = value;
+    if (threadIdx.x == 0) *b.count = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void bl_push(const BlockList &b, int value) { b.items[atomicAdd(b.count, 1)] = value; }
+__device__ __forceinline__ void bl_flush(const BlockList &b, int *__restrict__ list, int *__restrict__ counter)
+{
+    __syncthreads();
+    const int n = *b.count;
+    if (n == 0) return;
+    if (threadIdx.x == 0) *b.base = atomicAdd(counter, n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) list[*b.base + i] = b.items[i];
 }
 
+// a labelled pixel p of rank r pushes its undecided neighbours: key = r * 4 + slot, slot = position of the neighbour in
+// skimage's push order (up, left, right, down).  The first push of a pixel appends it to the next generation's list.
 __device__ __forceinline__ void mb_push_from(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
-                                             int *__restrict__ next, int *__restrict__ counter, int p, bool active, int Y, int X)
+                                             const BlockList &bl, int p, int Y, int X)
 {
-    // (all 64 lanes walk the four slots together -- the appends are wave-wide -- inactive lanes push nothing)
-    const unsigned long long s = active ? st[p] : 0ULL;
+    const unsigned long long s = st[p];
     const int l = st_lab(s);
-    active = active && l > 0;
+    if (l <= 0) return;
     const unsigned long long r4 = (unsigned long long)(unsigned)(st_tref(s) - 1) * 4ULL;
-    const int y = active ? p / X : 0, x = active ? p - y * X : 0;
+    const int y = p / X, x = p - y * X;
     const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int u = nb[k];
-        bool first = false;
-        if (active && u >= 0 && st[u] == 0ULL) {
-            const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
-            first = atomicMin(&cand[u], val) == MB_NONE;
-        }
-        wave_append(first, u, next, counter);
+        if (u < 0 || st[u] != 0ULL) continue;
+        const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
+        if (atomicMin(&cand[u], val) == MB_NONE) bl_push(bl, u);
     }
 }
 
 __global__ void __launch_bounds__(256) k_mb_push_markers(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
                                                          int *__restrict__ next, int *__restrict__ counter, int Y, int X)
 {
+    __shared__ int s_items[4 * 256], s_count, s_base;
+    const BlockList bl{s_items, &s_count, &s_base};
+    bl_init(bl);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    mb_push_from(st, cand, next, counter, y * X + min(x, X - 1), x < X, Y, X);
+    if (x < X) mb_push_from(st, cand, bl, y * X + x, Y, X);
+    bl_flush(bl, next, counter);
 }
 
 __global__ void __launch_bounds__(256) k_mb_push_list(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
                                                       const int *__restrict__ list, int nlist, int *__restrict__ next,
                                                       int *__restrict__ counter, int Y, int X)
 {
+    __shared__ int s_items[4 * 256], s_count, s_base;
+    const BlockList bl{s_items, &s_count, &s_base};
+    bl_init(bl);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    mb_push_from(st, cand, next, counter, i < nlist ? list[i] : 0, i < nlist, Y, X);
+    if (i < nlist) mb_push_from(st, cand, bl, list[i], Y, X);
+    bl_flush(bl, next, counter);
 }
 
 __global__ void __launch_bounds__(256) k_mb_flag_keys(const unsigned long long *__restrict__ cand, const int *__restrict__ next,
@@ -896,25 +915,36 @@ __device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst,
     return true;
 }
 
-// first pass, all pixels of the generation in parallel; the ones left waiting (chains of adjacent same-generation pixels
-// along collision fronts) are listed for the tail
+// One parallel pass over a list of the generation's pixels (list indices = ranks); the ones left waiting -- chains of
+// adjacent same-generation pixels along collision fronts, a pixel per pass -- are listed for the next pass.
+// src == nullptr: the whole generation (first pass); else the waiting list of the previous pass.
 __global__ void __launch_bounds__(256) k_mb_resolve(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                    const int *__restrict__ list, int nlist, int Y, int X, int *__restrict__ pend,
+                                                    const int *__restrict__ list, int nlist, const int *__restrict__ src,
+                                                    const int *__restrict__ nsrc, int Y, int X, int *__restrict__ pend,
                                                     int *__restrict__ npend)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool waiting = false;
-    if (i < nlist) {
-        const int p = list[i];
-        waiting = true;
-        for (int attempt = 0; attempt < 4 && waiting; ++attempt) waiting = !mb_try_resolve(st, cand, p, i + 1, Y, X);
+    __shared__ int s_items[4 * 256], s_count, s_base;
+    const BlockList bl{s_items, &s_count, &s_base};
+    const int n = src ? *nsrc : nlist;
+    // block-stride loop: later passes are launched for an expected count, whatever the real one is gets processed
+    for (int j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x) {
+        bl_init(bl);
+        const int j = j0 + threadIdx.x;
+        if (j < n) {
+            const int i = src ? src[j] : j;
+            const int p = list[i];
+            bool waiting = true;
+            for (int attempt = 0; attempt < 2 && waiting; ++attempt) waiting = !mb_try_resolve(st, cand, p, i + 1, Y, X);
+            if (waiting) bl_push(bl, i);
+        }
+        bl_flush(bl, pend, npend);
+        __syncthreads();
     }
-    wave_append(waiting, i, pend, npend);
 }
 
-// tail: ONE block sweeps the waiting pixels until all are decided (every sweep decides at least the smallest-ranked
-// one, so at most n sweeps; chains are a few dozen pixels long).  One block: no host round trip per sweep, and the
-// block's own stores are visible to its (volatile) loads after the barrier.
+// tail: ONE block sweeps what is still waiting after the parallel passes until all are decided (every sweep decides at
+// least the smallest-ranked one).  One block: no host round trip per sweep, and the block's own stores are visible to
+// its (volatile) loads after the barrier.
 __global__ void __launch_bounds__(1024) k_mb_resolve_tail(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
                                                           const int *__restrict__ list, const int *__restrict__ pend,
                                                           const int *__restrict__ npend, int Y, int X, WsInfo *info)
@@ -1004,12 +1034,13 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         unsigned char *c_d = ws.get<unsigned char>((size_t)M);
         unsigned *E_d = ws.get<unsigned>((size_t)M), *order_d = ws.get<unsigned>((size_t)M);
         unsigned long long *cand = ws.get<unsigned long long>(n);
-        int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1), *pend = isroot;   // (isroot is free here)
+        int *lists = ws.get<int>((size_t)2 * n), *counter = ws.get<int>(1), *pcount = ws.get<int>(16);
+        int *pendA = isroot, *pendB = flag;   // waiting lists of the resolve passes (isroot / flag are free here)
         // rank keys of a generation live in [0, 4 * size of the previous one): the markers first, later at most every
         // other pixel
         const size_t keycap = (size_t)4 * (size_t)std::max<long>(M, n - M) + 4;
         int *kflag = ws.get<int>(keycap), *drank = ws.get<int>(keycap);
-        if (!c_d || !E_d || !order_d || !cand || !lists || !counter || !kflag || !drank) return TIP_ERR_NOMEM;
+        if (!c_d || !E_d || !order_d || !cand || !lists || !counter || !pcount || !kflag || !drank) return TIP_ERR_NOMEM;
         TIP_LAUNCH("mb_push_counts", k_mb_push_counts, dim3(cdiv(X, 256), Y), dim3(256), 0, (const unsigned long long *)st,
                    (const int *)mrank, c_d, Y, X);
         {
@@ -1045,11 +1076,20 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             if ((rc = exclusive_scan_i32(kflag, drank, keyspace, nullptr))) return rc;
             TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
                        (const int *)unordered, nnext, (const int *)drank, next_list);
-            TIP_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));      // (nnext was read: the counter now counts waiting pixels)
-            TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
-                       (const int *)next_list, nnext, Y, X, pend, counter);
+            // fate of the generation: parallel passes that ping-pong the list of waiting pixels (no host round trip: every
+            // pass is launched for the worst case and reads its count on the device), then the one-block tail
+            constexpr int MB_PASSES = 6;
+            TIP_HIP(hipMemsetAsync(pcount, 0, (MB_PASSES + 1) * sizeof(int), s));
+            for (int pass = 0; pass < MB_PASSES; ++pass) {
+                int *dst = pass & 1 ? pendB : pendA;
+                const int *src = pass == 0 ? nullptr : (pass & 1 ? pendA : pendB);
+                TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(pass == 0 ? nnext : std::max(1, nnext >> pass), 256)), dim3(256), 0, st,
+                           (const unsigned long long *)cand, (const int *)next_list, nnext, src, (const int *)(pcount + pass), Y, X,
+                           dst, pcount + pass + 1);
+            }
             TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
-                       (const int *)next_list, (const int *)pend, (const int *)counter, Y, X, info);
+                       (const int *)next_list, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), (const int *)(pcount + MB_PASSES), Y,
+                       X, info);
             std::swap(cur_list, next_list);
             ncur = nnext;
             keyspace = 4L * nnext;

@@ -242,22 +242,16 @@ class TissueHipMixin(object):
         cells_info = self.get_cells_info(frame)
         if labels is None or cells_info is None:
             return 0
-        lab32 = np.ascontiguousarray(labels, dtype=np.int32)
-        mx = seg.maximum_filter(lab32, footprint=True, mode="constant")
-        lc = lab32.copy()
-        lc[lc == 0] = np.max(lc) + 1
-        mn = seg.minimum_filter(lc, footprint=True, mode="constant")
+        # the reference counts, inside every cell's bounding box, the pixels whose cross-footprint (max, min) of the labels
+        # is the pair (larger, smaller): such a pixel touches both cells, hence lies in the box -- the count is a property
+        # of the label map, taken in one device pass (tip_contact_pairs_i32)
+        length = seg.contact_pairs(labels)
         max_index = cells_info.index.max()
         output = np.zeros((max_index + 1, max_index + 1))
-        for index, cell in cells_info.iterrows():
-            r0 = int(max(0, cell.bounding_box_min_row - 2))
-            r1 = int(cell.bounding_box_max_row + 2)
-            c0 = int(max(0, cell.bounding_box_min_col - 2))
-            c1 = int(cell.bounding_box_max_col + 2)
-            mxr, mnr = mx[r0:r1, c0:c1], mn[r0:r1, c0:c1]
-            for nb in cell.neighbors:
-                hi, lo = max(index + 1, nb), min(index + 1, nb)
-                output[index, nb - 1] = np.sum(np.logical_and(mxr == hi, mnr == lo))
+        for index, neighbors in zip(cells_info.index.to_numpy(), cells_info["neighbors"].to_numpy()):
+            me = int(index) + 1
+            for nb in neighbors:
+                output[index, nb - 1] = length.get((max(me, nb), min(me, nb)), 0)
         return output
 
     # ---- T3 -------------------------------------------------------------------------------------------------
