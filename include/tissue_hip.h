@@ -160,6 +160,12 @@ TIP_API int tip_regionprops_i32_dev(const int32_t *labels, const double *intensi
 TIP_API int tip_neighbor_pairs_i32(const int32_t *labels, int y, int x, int32_t *pairs, int64_t cap, int64_t *n_pairs);
 TIP_API int tip_neighbor_pairs_i32_dev(const int32_t *labels, int y, int x, int32_t *pairs_dev, int64_t cap,
                                        int64_t *n_pairs_host);
+/* Exact order statistics per label (calc_cell_types' per-cell np.percentile, ti.py:2349-2355) by radix select:       */
+/* lo[l] = the value of 0-based rank ranks[l] among the pixels of label l+1 of img (float64), hi[l] = the value of rank */
+/* ranks[l]+1 (= lo[l] when the label has no such pixel); ranks[l] < 0 skips label l+1.  labels == NULL: nlab must be 1 */
+/* and the statistic is taken over the whole frame (np.percentile(img, 99), ti.py:2371).                               */
+TIP_API int tip_label_order_stats_f64(const int32_t *labels, const double *img, int y, int x, int nlab, const int64_t *ranks,
+                                      double *lo, double *hi);
 /* Contact lengths (ti.py:1844-1872, 4073-4094): for every ordered label pair (hi > lo >= 1) the number of pixels whose  */
 /* 4-neighbour maximum of the labels is hi and whose 4-neighbour minimum of the labels with zeros replaced by `big`    */
 /* (= max label + 1, ti.py:4081) is lo; filters as scipy's with the cross footprint and mode='constant'.  pairs: (hi, */

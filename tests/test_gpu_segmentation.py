@@ -315,6 +315,34 @@ def test_celltypes_pins(env, golden):
     assert types.shape == lab.shape
 
 
+def test_percentiles_by_radix_select_equal_numpy(env, golden):
+    """C5's dense part: np.percentile per label and over the frame (ti.py:2349-2355, 2371) from exact order statistics
+    found by radix select on the device; values with many ties, negative values, single-pixel labels, absent labels."""
+    _, seg, _, _ = env
+    g = golden("celltypes")
+    lab, inten = g["labels"], g["intensity"]
+    n = int(lab.max())
+    counts = np.bincount(lab.ravel(), minlength=n + 1)[1:]
+    np.testing.assert_array_equal(seg.percentile_per_label(lab, inten, n, counts, 10), g["p10"])
+    assert seg.percentile_frame(inten, 99) == float(g["p99"])
+    rng = np.random.default_rng(2)
+    lab2 = rng.integers(0, 400, (300, 500)).astype(np.int32)
+    lab2[lab2 == 17] = 0                                      # label 17 absent
+    lab2[0, 0] = 399
+    img = np.round(rng.normal(0, 50, lab2.shape))             # integers around zero: heavy ties, both signs
+    img[5:40, 5:90] = -0.0
+    n2 = 400
+    c2 = np.bincount(lab2.ravel(), minlength=n2 + 1)[1:]
+    for q in (0, 10, 37.5, 50, 99, 100):
+        want = np.array([np.percentile(img[lab2 == l], q) if c2[l - 1] else np.nan for l in range(1, n2 + 1)])
+        got = seg.percentile_per_label(lab2, img, n2, c2, q)
+        np.testing.assert_array_equal(got, want)
+        assert seg.percentile_frame(img, q) == np.percentile(img, q)
+    big = rng.random((1200, 1500)) * 1e6
+    for q in (1, 99):
+        assert seg.percentile_frame(big, q) == np.percentile(big, q)
+
+
 def test_tracking_golden(env, golden):
     _, _, ti, _ = env
     g = golden("tracking")

@@ -191,3 +191,46 @@ def contact_pairs(labels, cap=None):
         break
     k = int(n.value)
     return {(int(h), int(l)): int(c) for (h, l), c in zip(pairs[:k].tolist(), counts[:k].tolist())}
+
+
+def label_order_stats(labels, img, nlab, ranks):
+    """(lo, hi): per label l+1 the values of 0-based ranks ranks[l] and ranks[l] + 1 among img's pixels of that label
+    (hi == lo when there is no next one); ranks[l] < 0 skips the label.  labels None: one rank over the whole frame."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+    lo = np.empty(nlab, np.float64)
+    hi = np.empty(nlab, np.float64)
+    _lib.check(_lib.lib().tip_label_order_stats_f64(_lib.ptr(lab), _lib.ptr(img), img.shape[0], img.shape[1], int(nlab),
+                                                    _lib.ptr(ranks), _lib.ptr(lo), _lib.ptr(hi)))
+    return lo, hi
+
+
+def _lerp_percentile(lo, hi, gamma):
+    """numpy's 'linear' percentile from the two neighbouring order statistics (function_base._lerp)."""
+    diff = hi - lo
+    return np.where(gamma >= 0.5, hi - diff * (1 - gamma), lo + diff * gamma)
+
+
+def percentile_per_label(labels, img, nlab, counts, q):
+    """np.percentile(img[labels == l + 1], q) for every label with counts[l] > 0 (others: nan), exact."""
+    counts = np.asarray(counts, dtype=np.int64)
+    present = counts > 0
+    virt = (counts - 1) * (q / 100.0)
+    prev = np.clip(np.floor(virt).astype(np.int64), 0, np.maximum(counts - 1, 0))
+    gamma = virt - np.floor(virt)
+    lo, hi = label_order_stats(labels, img, nlab, np.where(present, prev, -1))
+    hi = np.where(prev + 1 <= counts - 1, hi, lo)
+    return np.where(present, _lerp_percentile(lo, hi, gamma), np.nan)
+
+
+def percentile_frame(img, q):
+    """np.percentile(img, q) over all pixels, exact (radix select on the device, numpy's interpolation on the host)."""
+    img = np.asarray(img)
+    n = img.size
+    virt = (n - 1) * (q / 100.0)
+    prev = int(np.floor(virt))
+    gamma = virt - np.floor(virt)
+    lo, hi = label_order_stats(None, img.reshape(1, -1) if img.ndim != 2 else img, 1, np.array([prev], np.int64))
+    hi = hi if prev + 1 <= n - 1 else lo
+    return float(_lerp_percentile(lo, hi, gamma)[0])

@@ -8,7 +8,7 @@ reference's state / cache / persistence code (ti.py:193-353, 3462-3823) stays th
     calculate_frame_cellinfo(frame_number)                 ti.py:880-909   -> tip_regionprops_i32 + tip_neighbor_pairs_i32
     find_neighbors(frame_number, only_for_labels=None)     ti.py:1815-1842 -> tip_neighbor_pairs_i32
     update_labels(frame)                                   ti.py:2967-2975 -> tip_update_labels_i32
-    calc_cell_types(...), update_cell_types_by_cells_info  ti.py:2338-2408 -> tip_regionprops_i32 (+ host order statistics)
+    calc_cell_types(...), update_cell_types_by_cells_info  ti.py:2338-2408 -> tip_regionprops_i32 + tip_label_order_stats_f64
     calc_neighbors_contact_matrix(frame)                   ti.py:4073-4094 -> tip_rankfilter2d (cross footprint)
     track_cells_iterator(...)                              ti.py:2037-2113 -> tip_rankfilter2d + host table logic
     get_trackking_labels(frame)                            ti.py:4021-4028 -> tip_lut_gather_i32
@@ -170,20 +170,10 @@ class TissueHipMixin(object):
         rp = seg.regionprops_arrays(labels, intensity=img)
         present = rp["area"] > 0
         cell_indices = np.nonzero(present)[0]
-        # per-label percentile(100 - p): order statistic of each region's pixels (host: one sort for all regions)
-        flat_l = np.asarray(labels).ravel()
-        order = np.lexsort((img.ravel(), flat_l))
-        sl, sv = flat_l[order], img.ravel()[order]
-        starts = np.searchsorted(sl, cell_indices + 1, side="left")
-        counts = rp["area"][cell_indices]
-        q = (100 - percentage_above_threshold) / 100.0
-        virt = (counts - 1) * q
-        prev = np.clip(np.floor(virt).astype(np.int64), 0, counts - 1)
-        nxt = np.minimum(prev + 1, counts - 1)
-        gamma = virt - np.floor(virt)
-        lo, hi = sv[starts + prev], sv[starts + nxt]
-        diff = hi - lo
-        marker_intensities = np.where(gamma >= 0.5, hi - diff * (1 - gamma), lo + diff * gamma)
+        # per-label percentile(100 - p): two neighbouring order statistics of each region's pixels by radix select on the
+        # device (tip_label_order_stats_f64), numpy's linear interpolation between them on the host
+        marker_intensities = seg.percentile_per_label(labels, img, rp["area"].size, rp["area"],
+                                                      100 - percentage_above_threshold)[cell_indices]
         if new_type:
             cells_info.loc[cell_indices, "mean_intensity_" + type_name] = rp["intensity_mean"][cell_indices]
         areas = cells_info.area.to_numpy()
@@ -196,7 +186,7 @@ class TissueHipMixin(object):
         self.find_neighbors(frame_number, only_for_labels=updated_labels)
         cells_info = self.get_cells_info(frame_number)
         cells_info.loc[:, "valid"] = new_valid.astype(int)
-        max_brightness = np.percentile(img, 99)
+        max_brightness = seg.percentile_frame(img, 99)
         thr = threshold * max_brightness
         pos_indices = cell_indices[marker_intensities > thr]
         neg_indices = cell_indices[marker_intensities <= thr]

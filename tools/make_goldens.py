@@ -156,6 +156,48 @@ def gold_projection_binned():
     save("projection_binned", **out)
 
 
+def gold_display_ops():
+    """f4 / f1 array operations of basic_image_manipulations.py: band_pass_filter (bim.py:393-414), set_brightness /
+    set_channel_brightness (bim.py:233-348) and the uint16 / uint8 normalisation save_tiff applies before writing
+    (bim.py:183-188; the OME writer itself is stubbed out)."""
+    rng = np.random.default_rng(41)
+    out = {}
+    f64 = rng.random((60, 75)) * 900.0
+    u16 = rng.integers(0, 40000, (50, 64)).astype(np.uint16)
+    f32 = (rng.random((40, 48)) * 3.0).astype(np.float32)
+    out.update(bp_f64=f64, bp_u16=u16, bp_f32=f32)
+    out["bp_f64_out"] = bim.band_pass_filter(f64, 1.0, 4.0)
+    out["bp_u16_out"] = bim.band_pass_filter(u16, 2.0, 3.5)
+    out["bp_f32_out"] = bim.band_pass_filter(f32, 0.5, 2.0)
+    mov = rng.integers(100, 30000, (2, 3, 40, 52)).astype(np.uint16)            # T C Y X
+    out["sb_movie"] = mov
+    out["sb_bestfit"] = bim.set_brightness(mov.copy(), "TCYX")
+    out["sb_minmax0"] = bim.set_brightness(mov.copy(), "TCYX", method="minMax", clearExtreamPrecentage=0)
+    img8 = rng.integers(0, 255, (33, 47)).astype(np.uint8)
+    out["sb_u8"] = img8
+    out["sb_u8_out"] = bim.set_brightness(img8.copy(), "YX", clearExtreamPrecentage=5, minVal=20)
+    adj, meta = bim.set_brightness(mov.copy(), "TCYX", metadata={"min": 150, "max": 30000, "Ranges": (0, 1, 0, 1)})
+    out["sb_meta_out"] = adj
+    out["sb_meta_max"] = np.array(meta["max"])
+    captured = {}
+
+    class _Writer(object):
+        @staticmethod
+        def save(image, path, dim_order=None, ome_xml=None):
+            captured["image"] = image
+
+    bim.ome_tiff_writer = types.SimpleNamespace(OmeTiffWriter=_Writer)
+    proj = rng.random((2, 30, 36)) * 5000.0
+    out["st_in"] = proj
+    bim.save_tiff("x.tif", proj, axes="CYX", data_type="uint16")
+    out["st_u16"] = captured["image"]
+    bim.save_tiff("x.tif", proj, axes="CYX", data_type="uint8")
+    out["st_u8"] = captured["image"]
+    bim.save_tiff("x.tif", u16, axes="YX", data_type="uint16")                    # already uint16: untouched
+    out["st_same"] = captured["image"]
+    save("display_ops", **out)
+
+
 def gold_rank_filters():
     rng = np.random.default_rng(21)
     lab = rng.integers(0, 40, (37, 53)).astype(np.int32)
@@ -516,6 +558,7 @@ if __name__ == "__main__":
     pa, pf = gold_projection()
     gold_projection_binned()
     gold_rank_filters()
+    gold_display_ops()
     gold_label()
     la, lb = gold_watershed(pa, pf)
     gold_cellinfo(la, lb)
