@@ -111,6 +111,12 @@ TIP_API int tip_project_u16_hist_dev(const uint16_t *czyx, int c, int z, int y, 
                                      const double *t05, const double *t1, const double *t2, const double *t30,
                                      const unsigned long long *hist_dev, double *proj, int64_t *zmap);
 
+/* ---- U-Net convolution epilogue (pl.py:31-37): x = relu(x + bias[c]) * scale[c] + shift[c] in place on a channels-last */
+/* float32 activation of n values with c channels (c % 4 == 0), launched on `stream` (a hipStream_t; NULL: the calling  */
+/* thread's stream).  The convolutions themselves run in PyTorch-ROCm / MIOpen.                                          */
+TIP_API int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const float *scale, const float *shift, long n, int c,
+                                         void *stream);
+
 /* ---- rank filters ---------------------------------------------------------------------------- */
 /* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */
 /* skimage.morphology.erosion/dilation with a flat footprint (pl.py:170-193).                     */

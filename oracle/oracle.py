@@ -98,6 +98,81 @@ def blur_image(image, std):
     return gaussian_filter(image, std, mode="nearest")
 
 
+# ----------------------------------------------------------------------------- display operations (bim.py:160-188, 233-414)
+def img_as_float(image):
+    """skimage.util.img_as_float as skimage.filters.gaussian applies it: unsigned integers are scaled by 1 / max of the
+    dtype in float64, floats pass through."""
+    image = np.asarray(image)
+    if image.dtype.kind == "u":
+        return np.multiply(image, 1.0 / np.iinfo(image.dtype).max, dtype=np.float64)
+    if image.dtype.kind == "f":
+        return image
+    raise NotImplementedError("oracle: unsigned integer or float images")
+
+
+def band_pass_filter(image, lowsigma, highsigma):
+    """bim.py:393-414 -> skimage.filters.difference_of_gaussians: gaussian(low) - gaussian(high), mode 'nearest'."""
+    f = img_as_float(image)
+    return gaussian_filter(f, lowsigma) - gaussian_filter(f, highsigma)
+
+
+def scoreatpercentile(a, per):
+    """scipy.stats.scoreatpercentile(a, per) ('fraction'): weights (j - idx, idx - i) on the two neighbouring order
+    statistics, divided by their sum."""
+    v = np.sort(np.ravel(a))
+    idx = per / 100.0 * (v.size - 1)
+    i = int(idx)
+    if i == idx:
+        return v[i] * 1.0 / 1.0
+    w = np.array([(i + 1) - idx, idx - i], float)
+    return np.add.reduce(v[i:i + 2] * w) / w.sum()
+
+
+def set_channel_brightness(image, max_possible_val, method="bestFit", clearExtreamPrecentage=1, minimum_pixel_val=0):
+    """bim.py:299-348 (float64 channel, modified in place like upstream).  adjust_gamma with gamma 1 is the identity."""
+    if clearExtreamPrecentage > 0:
+        new_maximum = scoreatpercentile(image, 100 - clearExtreamPrecentage)
+        new_minimum = scoreatpercentile(image, clearExtreamPrecentage)
+        if minimum_pixel_val > 0:
+            new_minimum = max(new_minimum, minimum_pixel_val)
+        image[image > new_maximum] = new_maximum
+    else:
+        new_minimum = minimum_pixel_val
+    if method in ("minMax", "bestFit"):
+        image = image - new_minimum
+        image = image / np.max(image)
+        image = image + 1 / max_possible_val
+        image[image < 0] = 0
+    return image
+
+
+def set_brightness(image, axes, metadata=None, method="bestFit", clearExtreamPrecentage=1, minVal=0, maxVal=0):
+    """bim.py:233-297."""
+    data_type = image.dtype
+    max_possible_val = maxVal if maxVal else (255 if data_type == "uint8" else 65535 if data_type == "uint16" else 1)
+    adjusted = np.copy(image).astype("double")
+    minimum_pixel_val = max(minVal, 0)
+    if metadata and "min" in metadata:
+        minimum_pixel_val = metadata["min"]
+    if axes.find("C") >= 0:
+        adjusted, order = put_channel_axis_first(adjusted, axes)
+        for ch in range(adjusted.shape[0]):
+            adjusted[ch] = set_channel_brightness(adjusted[ch], max_possible_val, method, clearExtreamPrecentage,
+                                                  minimum_pixel_val)
+        adjusted = np.transpose(adjusted, axes=np.argsort(order))
+    else:
+        adjusted = set_channel_brightness(adjusted, max_possible_val, method, clearExtreamPrecentage, minimum_pixel_val)
+    return adjusted
+
+
+def tiff_normalise(image, data_type):
+    """The conversion save_tiff applies before writing (bim.py:183-186)."""
+    if data_type and image.dtype != data_type and data_type in ("uint8", "uint16"):
+        top = 255 if data_type == "uint8" else 65535
+        return np.round((image / np.max(image)) * top).astype(data_type)
+    return image
+
+
 # ----------------------------------------------------------------------------- percentile (sp.py:33-36)
 def percentile_linear(a, q):
     """np.percentile(a, q) for a 1-D float array with numpy 1.26.4 arithmetic (the oracle interpreter):

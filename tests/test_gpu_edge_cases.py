@@ -162,3 +162,42 @@ def test_cell_tables_with_more_labels_than_tile_slots():
     gp = seg.neighbor_pairs(labels, cap=64 * int(labels.max()))
     wp = orc.neighbor_pairs(labels)
     assert set(map(tuple, np.asarray(gp).tolist())) == set(map(tuple, np.asarray(wp).tolist()))
+
+
+def test_display_ops_golden(env, golden, tmp_path):
+    """band_pass_filter, set_brightness (device order statistics + scipy's weighting), save_tiff's
+    normalisation and the self-contained TIFF writer, against the reference's own outputs."""
+    bim, _, _, _ = env
+    g = golden("display_ops")
+    np.testing.assert_array_equal(bim.band_pass_filter(g["bp_f64"], 1.0, 4.0), g["bp_f64_out"])
+    np.testing.assert_array_equal(bim.band_pass_filter(g["bp_u16"], 2.0, 3.0), g["bp_u16_out"])
+    out32 = bim.band_pass_filter(g["bp_f32"], 0.5, 2.0)
+    assert out32.dtype == np.float32
+    np.testing.assert_array_equal(out32, g["bp_f32_out"])
+    np.testing.assert_array_equal(bim.set_brightness(g["sb_movie"].copy(), "TCYX"), g["sb_bestfit"])
+    np.testing.assert_array_equal(bim.set_brightness(g["sb_movie"].copy(), "TCYX", method="minMax", clearExtreamPrecentage=0),
+                                  g["sb_minmax0"])
+    np.testing.assert_array_equal(bim.set_brightness(g["sb_u8"].copy(), "YX", clearExtreamPrecentage=5, minVal=20), g["sb_u8_out"])
+    adj, meta = bim.set_brightness(g["sb_movie"].copy(), "TCYX", metadata={"min": 150, "max": 30000, "Ranges": (0, 1, 0, 1)})
+    np.testing.assert_array_equal(adj, g["sb_meta_out"])
+    assert meta["max"] == int(g["sb_meta_max"]) and meta["min"] == 0 and meta["Ranges"] == (0, 65535, 0, 65535)
+    np.testing.assert_array_equal(bim.tiff_normalise(g["st_in"], "uint16"), g["st_u16"])
+    np.testing.assert_array_equal(bim.tiff_normalise(g["st_in"], "uint8"), g["st_u8"])
+    assert bim.tiff_normalise(g["bp_u16"], "uint16") is not None
+    np.testing.assert_array_equal(bim.tiff_normalise(g["bp_u16"], "uint16"), g["st_same"])
+    # the writer: pages come back as written (parsed here with struct; tifffile reads the same file in the build container)
+    import struct
+    path = str(tmp_path / "proj.tif")
+    bim.save_tiff(path, g["st_in"], axes="CYX", data_type="uint16")
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"II*\x00"
+    off, pages = struct.unpack("<I", raw[4:8])[0], []
+    while off:
+        n = struct.unpack("<H", raw[off:off + 2])[0]
+        tags = {}
+        for i in range(n):
+            tag, typ, cnt, val = struct.unpack("<HHII", raw[off + 2 + 12 * i:off + 14 + 12 * i])
+            tags[tag] = val
+        pages.append(np.frombuffer(raw[tags[273]:tags[273] + tags[279]], "<u2").reshape(tags[257], tags[256]))
+        off = struct.unpack("<I", raw[off + 2 + 12 * n:off + 6 + 12 * n])[0]
+    np.testing.assert_array_equal(np.stack(pages), g["st_u16"])

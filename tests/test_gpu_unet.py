@@ -132,3 +132,26 @@ def test_unet_leg_at_headline_size():
     print("unet leg 2048^2: %d labels, %.0f%% foreground, %.0f%% markers, mismatches %d" % (
         ref.max(), 100 * frac, 100 * float((boundary == 0).mean()), mism))
     assert mism == 0
+
+
+def test_fused_conv_epilogue_equals_torch_ops(monkeypatch):
+    """bias -> ReLU -> BN scale/shift in one in-place HIP pass (tip_bias_relu_affine_f32_dev, torch's current stream)
+    is bit-identical to the torch expressions it replaces, and so is the whole network with either epilogue."""
+    import torch
+    from tissue_image_processing_amd import prediction_local as pl
+    net = pl._UNet(2, torch.device("cuda", 0), dtype=torch.float32, seed=5)
+    g = torch.Generator().manual_seed(1)
+    for name in list(net.p):                      # non-trivial BN statistics and biases
+        if name.endswith(".s") or name.endswith(".t") or name.endswith(".b"):
+            net.p[name] = (net.p[name] + 0.3 * torch.randn(net.p[name].shape, generator=g).to(net.p[name])).contiguous()
+    x = torch.randn((1, 128, 37, 52), generator=g).to("cuda").contiguous(memory_format=torch.channels_last)
+    b, s, t = net.p["d0.c2.b"], net.p["d0.b2.s"], net.p["d0.b2.t"]
+    want = torch.nn.functional.relu(x + b.view(1, -1, 1, 1)) * s + t
+    got = net._epilogue(x.clone(memory_format=torch.channels_last), b, s, t)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    inp = torch.rand((1, 2, 64, 96), generator=g).to("cuda")
+    fused = net.forward(inp)
+    monkeypatch.setenv("TISSUE_HIP_UNET_TORCH_EPILOGUE", "1")
+    plain = net.forward(inp)
+    assert torch.equal(fused, plain)

@@ -107,6 +107,24 @@ def test_projection_binned_three_channels_airyscan(golden):
         orc.time_point_surface_projection(g["h_stack"].copy(), "CZYX", 0, airyscan=True, method="nope", bin_size=2)
 
 
+def test_display_ops(golden, oracle_with_golden_taps):
+    """band_pass_filter, set_brightness, save_tiff's normalisation (bim.py:160-188, 233-414) from the reference itself."""
+    o = oracle_with_golden_taps
+    g = golden("display_ops")
+    np.testing.assert_array_equal(o.band_pass_filter(g["bp_f64"], 1.0, 4.0), g["bp_f64_out"])
+    np.testing.assert_array_equal(o.band_pass_filter(g["bp_u16"], 2.0, 3.0), g["bp_u16_out"])
+    np.testing.assert_array_equal(o.band_pass_filter(g["bp_f32"], 0.5, 2.0), g["bp_f32_out"])
+    np.testing.assert_array_equal(o.set_brightness(g["sb_movie"].copy(), "TCYX"), g["sb_bestfit"])
+    np.testing.assert_array_equal(o.set_brightness(g["sb_movie"].copy(), "TCYX", method="minMax", clearExtreamPrecentage=0),
+                                  g["sb_minmax0"])
+    np.testing.assert_array_equal(o.set_brightness(g["sb_u8"].copy(), "YX", clearExtreamPrecentage=5, minVal=20), g["sb_u8_out"])
+    np.testing.assert_array_equal(o.set_brightness(g["sb_movie"].copy(), "TCYX", metadata={"min": 150, "max": 30000}),
+                                  g["sb_meta_out"])
+    np.testing.assert_array_equal(o.tiff_normalise(g["st_in"], "uint16"), g["st_u16"])
+    np.testing.assert_array_equal(o.tiff_normalise(g["st_in"], "uint8"), g["st_u8"])
+    np.testing.assert_array_equal(o.tiff_normalise(g["bp_u16"], "uint16"), g["st_same"])
+
+
 def test_rank_filters(golden):
     g = golden("rank_filters")
     lab, img = g["lab"], g["img"]

@@ -119,3 +119,137 @@ def calculate_drift(first_image, second_image, sub_pixel_precision=True):
     else:
         shift, error, diffphase = phase_cross_correlation(first_image, second_image)
     return shift[-2:]
+
+
+# ---- display / export array operations ------------------------------------------------------------
+def _as_float_like_skimage(image):
+    """skimage.util.img_as_float as skimage.filters.gaussian applies it (unsigned integers scaled by 1 / dtype max in
+    float64, floats untouched)."""
+    image = np.asarray(image)
+    if image.dtype.kind == "u":
+        return np.multiply(image, 1.0 / np.iinfo(image.dtype).max, dtype=np.float64)
+    if image.dtype.kind == "f":
+        return image
+    raise TypeError("band_pass_filter on MI355X takes unsigned integer or float images (got %s)" % image.dtype)
+
+
+def band_pass_filter(image, lowsigma, highsigma):
+    """bim.py:393-414: skimage.filters.difference_of_gaussians = gaussian(low) - gaussian(high), edges replicated.
+    Both blurs run on the device with scipy's exact tap arithmetic (blur_image)."""
+    f = _as_float_like_skimage(image)
+    if np.any(np.asarray(highsigma, dtype=float) < np.asarray(lowsigma, dtype=float)):
+        raise ValueError("high_sigma must be equal to or larger thanlow_sigma for all axes")   # skimage's wording
+    return blur_image(f, lowsigma) - blur_image(f, highsigma)
+
+
+def _scoreatpercentile(values, per):
+    """scipy.stats.scoreatpercentile (default 'fraction' interpolation): the two neighbouring order statistics come from
+    the device (radix select, no sort), scipy's weighting from the host."""
+    from . import _segmentation as seg
+    flat = np.ascontiguousarray(values, dtype=np.float64).reshape(1, -1)
+    idx = per / 100.0 * (flat.size - 1)
+    i = int(idx)
+    lo, hi = seg.label_order_stats(None, flat, 1, np.array([i], np.int64))
+    if i == idx:
+        return lo[0]
+    w = np.array([(i + 1) - idx, idx - i], float)
+    return np.add.reduce(np.array([lo[0], hi[0]]) * w) / w.sum()
+
+
+def set_channel_brightness(image, max_possible_val, method='bestFit', clearExtreamPrecentage=1, minimum_pixel_val=0):
+    """bim.py:299-348: saturate the extreme percentiles, shift / scale to [0, 1] (+ 1 / max_possible_val).  `image` is a
+    float64 channel and is clipped in place like upstream; skimage's adjust_gamma with gamma 1 is the identity."""
+    if clearExtreamPrecentage > 0:
+        new_maximum = _scoreatpercentile(image, 100 - clearExtreamPrecentage)
+        new_minimum = _scoreatpercentile(image, clearExtreamPrecentage)
+        if minimum_pixel_val > 0:
+            new_minimum = max(new_minimum, minimum_pixel_val)
+        image[image > new_maximum] = new_maximum
+    else:
+        new_minimum = minimum_pixel_val
+    if method in ('minMax', 'bestFit'):
+        image = image - new_minimum
+        image = image / np.max(image)
+        image = image + 1 / max_possible_val
+        image[image < 0] = 0
+    return image
+
+
+def set_brightness(image, axes, metadata={}, method='bestFit', clearExtreamPrecentage=1, minVal=0, maxVal=0):
+    """bim.py:233-297: per-channel brightness adjustment to floats in [0, 1]; with metadata, (image, adjusted copy of it)."""
+    from copy import deepcopy
+    kind = np.asarray(image).dtype
+    top = maxVal if maxVal else (255 if kind == np.uint8 else 65535 if kind == np.uint16 else 1)
+    adjusted = np.array(image, dtype=np.float64)
+    floor = metadata['min'] if (metadata and 'min' in metadata) else max(minVal, 0)
+    if axes.find("C") >= 0:
+        adjusted, order = put_channel_axis_first(adjusted, axes)
+        for channel in range(adjusted.shape[0]):
+            adjusted[channel] = set_channel_brightness(adjusted[channel], top, method, clearExtreamPrecentage, floor)
+        adjusted = np.transpose(adjusted, axes=np.argsort(order))
+    else:
+        adjusted = set_channel_brightness(adjusted, top, method, clearExtreamPrecentage, floor)
+    if not metadata:
+        return adjusted
+    meta = deepcopy(metadata)
+    if 'min' in meta:
+        meta['min'] = 0
+    if 'max' in meta:
+        meta['max'] = top
+    if 'Ranges' in meta:
+        meta['Ranges'] = (0, top) * int(len(meta['Ranges']) // 2)
+    return adjusted, meta
+
+
+def tiff_normalise(image, data_type=""):
+    """The conversion save_tiff applies before writing (bim.py:183-186): images that are not already of the requested
+    unsigned type are scaled so that their maximum becomes the type's maximum, and rounded."""
+    image = np.asarray(image)
+    if data_type and image.dtype != data_type and data_type in ('uint8', 'uint16'):
+        top = 255 if data_type == 'uint8' else 65535
+        image = np.round((image / np.max(image)) * top).astype(data_type)
+    return image
+
+
+def save_tiff(path, image, metadata=None, axes="", data_type=""):
+    """bim.py:160-188.  Upstream hands the array to aicsimageio's OME-TIFF writer; here a self-contained baseline TIFF
+    writer stores every (Y, X) plane of the normalised array as one page (little-endian, uncompressed, min-is-black) with
+    the axes string and shape in the first page's ImageDescription -- what ImageJ / tifffile / the reference's read_tiff
+    open as a stack.  OME-XML metadata is not written."""
+    import struct
+    image = tiff_normalise(image, data_type)
+    if image.dtype == np.float64:
+        image = image.astype(np.float32)
+    if image.dtype not in (np.uint8, np.uint16, np.float32, np.int32):
+        raise TypeError("save_tiff writes uint8 / uint16 / int32 / float32 pages (got %s)" % image.dtype)
+    if image.ndim < 2:
+        raise ValueError("save_tiff needs at least a 2-D image")
+    planes = np.ascontiguousarray(image).reshape((-1,) + image.shape[-2:]).astype(image.dtype.newbyteorder("<"))
+    rows, cols = planes.shape[1:]
+    bits = planes.dtype.itemsize * 8
+    fmt = 3 if planes.dtype.kind == "f" else (2 if planes.dtype.kind == "i" else 1)
+    desc = ("axes=%s shape=%s" % (axes, "x".join(str(v) for v in image.shape))).encode("ascii") + b"\0"
+    if planes.nbytes + planes.shape[0] * 256 + len(desc) >= 2 ** 32:
+        raise ValueError("save_tiff: classic TIFF holds less than 4 GiB; split the movie")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<2sHI", b"II", 42, 8))
+        offset = 8
+        for k in range(planes.shape[0]):
+            entries = [(256, 4, 1, cols), (257, 4, 1, rows), (258, 3, 1, bits), (259, 3, 1, 1), (262, 3, 1, 1),
+                       (277, 3, 1, 1), (278, 4, 1, rows), (279, 4, 1, rows * cols * planes.dtype.itemsize), (339, 3, 1, fmt)]
+            extra = desc if k == 0 else b""
+            ifd_size = 2 + 12 * (len(entries) + 1 + (1 if extra else 0)) + 4
+            data_at = offset + ifd_size + len(extra)
+            entries.append((273, 4, 1, data_at))
+            if extra:
+                entries.append((270, 2, len(extra), offset + ifd_size))
+            entries.sort()
+            nxt = data_at + rows * cols * planes.dtype.itemsize if k + 1 < planes.shape[0] else 0
+            fh.write(struct.pack("<H", len(entries)))
+            for tag, typ, cnt, val in entries:
+                fh.write(struct.pack("<HHII", tag, typ, cnt, val))
+            fh.write(struct.pack("<I", nxt))
+            fh.write(extra)
+            fh.write(planes[k].tobytes())
+            offset = nxt
+    return

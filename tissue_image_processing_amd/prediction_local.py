@@ -140,12 +140,28 @@ class _UNet(object):
             c = f
         conv("head", c, 2, 1)
 
+    def _epilogue(self, x, bias, scale, shift):
+        """Conv2D's bias -> ReLU -> BatchNormalization (inference: per-channel scale and shift).  float32 on the GPU: one
+        in-place pass in libtissue_hip.so on torch's current stream (same float32 operations in the same order as the
+        four torch passes it replaces); otherwise the torch expressions."""
+        torch = self.torch
+        if (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[0] == 1 and
+                x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("TISSUE_HIP_UNET_TORCH_EPILOGUE") != "1"):
+            lib = _lib.lib()
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.tip_bias_relu_affine_f32_dev(_lib.dptr(x.data_ptr()), _lib.dptr(bias.data_ptr()),
+                                                        _lib.dptr(scale.data_ptr()), _lib.dptr(shift.data_ptr()),
+                                                        ctypes.c_long(x.numel()), int(x.shape[1]), ctypes.c_void_p(stream)))
+            return x
+        x = torch.nn.functional.relu(x + bias.view(1, -1, 1, 1))
+        return x * scale + shift
+
     def _double(self, x, name):
         F = self.torch.nn.functional
         p = self.p
         for k in ("1", "2"):
-            x = F.relu(F.conv2d(x, p[name + ".c" + k + ".w"], p[name + ".c" + k + ".b"], padding=1))
-            x = x * p[name + ".b" + k + ".s"] + p[name + ".b" + k + ".t"]
+            x = F.conv2d(x, p[name + ".c" + k + ".w"], None, padding=1)
+            x = self._epilogue(x, p[name + ".c" + k + ".b"], p[name + ".b" + k + ".s"], p[name + ".b" + k + ".t"])
         return x
 
     def calibrate_head(self, x, fraction):

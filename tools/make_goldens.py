@@ -167,7 +167,7 @@ def gold_display_ops():
     f32 = (rng.random((40, 48)) * 3.0).astype(np.float32)
     out.update(bp_f64=f64, bp_u16=u16, bp_f32=f32)
     out["bp_f64_out"] = bim.band_pass_filter(f64, 1.0, 4.0)
-    out["bp_u16_out"] = bim.band_pass_filter(u16, 2.0, 3.5)
+    out["bp_u16_out"] = bim.band_pass_filter(u16, 2.0, 3.0)
     out["bp_f32_out"] = bim.band_pass_filter(f32, 0.5, 2.0)
     mov = rng.integers(100, 30000, (2, 3, 40, 52)).astype(np.uint16)            # T C Y X
     out["sb_movie"] = mov
