@@ -124,9 +124,15 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
     use_dist = world > 1
     sites_t, is_hc = synthetic.make_movie_sites(Y, X, T, seed=5)
     mine = list(range(rank, T, world))
-    stacks = {t: synthetic.make_stack(Z, Y, X, seed=200 + t, sites=sites_t[t], is_hc=is_hc) for t in mine}
-    backend = movie.GpuFrameBackend(2, Z, Y, X, device=local_rank, keep_planes=True)
-    backend.process_frame(-1, stacks[mine[0]])        # warm-up (allocations)
+    # the movie's frames wait in pinned host memory (where a reader thread would put them); every frame's host->device
+    # copy is inside the timed region
+    stacks = {t: torch.from_numpy(synthetic.make_stack(Z, Y, X, seed=200 + t, sites=sites_t[t], is_hc=is_hc)).pin_memory()
+              for t in mine}
+    backend = movie.GpuFrameBackend(2, Z, Y, X, device=local_rank, keep_planes=True, inflight=args.inflight)
+    backend.process_frames([-1 - k for k in range(min(args.inflight, len(mine)))], lambda t: stacks[mine[0]])   # warm-up
+    for k in range(args.inflight):
+        backend.labels.pop(-1 - k, None)
+        backend.planes.pop(-1 - k, None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -147,7 +153,8 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": T / elapsed, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d_c2_u16:movie(%d frames, host upload included)+drift estimation+track_stitching" % (Y, X, Z, T),
+            "config": {"workload": "%dx%dx%d_c2_u16:movie(%d frames, host upload from pinned memory included)+drift estimation+track_stitching" % (Y, X, Z, T),
+                       "frames_in_flight_per_gpu": args.inflight,
                        "parallelism": "frame-sharded dp%d, neighbour-rank plane exchange for the drift, RCCL gather of "
                                       "per-frame tables to rank 0" % world,
                        "mean_abs_drift": [float(v) for v in np.mean(np.abs([tb["drift"] for tb in tabs[1:]]), axis=0)],

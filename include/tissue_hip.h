@@ -112,8 +112,8 @@ TIP_API int tip_project_u16_hist_dev(const uint16_t *czyx, int c, int z, int y, 
                                      const unsigned long long *hist_dev, double *proj, int64_t *zmap);
 
 /* ---- U-Net convolution epilogue (pl.py:31-37): x = relu(x + bias[c]) * scale[c] + shift[c] in place on a channels-last */
-/* float32 activation of n values with c channels (c % 4 == 0), launched on `stream` (a hipStream_t; NULL: the calling  */
-/* thread's stream).  The convolutions themselves run in PyTorch-ROCm / MIOpen.                                          */
+/* float32 activation of n values with c channels (c % 4 == 0), launched on `stream` (a hipStream_t taken as is: NULL is */
+/* HIP's null stream, torch's default).  The convolutions themselves run in PyTorch-ROCm / MIOpen.                       */
 TIP_API int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const float *scale, const float *shift, long n, int c,
                                          void *stream);
 

@@ -24,7 +24,7 @@ def main():
     d = dist if world > 1 else None
     tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, d, "cpu", drifts)
     # the same movie with the drift ESTIMATED inside the sharded driver (planes exchanged between the ranks)
-    backend2 = movie.GpuFrameBackend(2, Z, Y, X, device=0, keep_planes=True)
+    backend2 = movie.GpuFrameBackend(2, Z, Y, X, device=0, keep_planes=True, inflight=2)   # two frames in flight per process
     tabs_e, ids_e = movie.process_movie(T, lambda t: stacks[t], backend2, rank, world, d, "cpu", estimate_drift=True)
     if rank == 0:
         np.savez(out_path, n=T, **{"ids_%d" % t: ids[t] for t in range(T)}, **{"area_%d" % t: tabs[t]["area"] for t in range(T)},

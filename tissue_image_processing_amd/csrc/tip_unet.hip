@@ -34,14 +34,15 @@ using namespace tip;
 extern "C" {
 
 // x: n float32 values of a channels-last (NHWC-contiguous) activation with C channels, updated in place:
-// x = relu(x + bias[c]) * scale[c] + shift[c].  `stream`: the hipStream_t to launch on (0: the calling thread's).
+// x = relu(x + bias[c]) * scale[c] + shift[c].  `stream`: the hipStream_t to launch on, taken as is -- 0 is HIP's null
+// stream, which is what torch.cuda.current_stream() is unless the caller changed it.
 int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const float *scale, const float *shift, long n, int c, void *stream)
 {
     Ctx &cx = ctx();
     if (!cx.stream) return TIP_ERR_HIP;
     if (!x || !bias || !scale || !shift || n < 0 || c < 4 || (c & 3) || (n % c)) return fail(TIP_ERR_ARG, "bias_relu_affine: bad arguments");
     if (n == 0) return TIP_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : cx.stream;
+    hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bias_relu_affine_f32, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, x, bias, scale, shift, n / 4, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TIP_ERR_HIP, "launch bias_relu_affine: %s", hipGetErrorString(e));

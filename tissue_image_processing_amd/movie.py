@@ -26,18 +26,66 @@ class GpuFrameBackend(object):
     frame: the int32 label map (tracker look-ups) and, when drift is estimated, the reference channel's projection plane
     -- both kept with device-to-device copies.  The planes are torch tensors so that RCCL can send them as they are."""
 
-    def __init__(self, C, Z, Y, X, device=None, keep_planes=False, **kw):
+    def __init__(self, C, Z, Y, X, device=None, keep_planes=False, inflight=1, **kw):
         from .pipeline import FramePipeline
+        from . import _lib
+        self._shape, self._kw = (C, Z, Y, X), kw
+        self.device = device
         self.pipe = FramePipeline(C, Z, Y, X, device=device, **kw)
+        if device is None:
+            self.device = _lib.device_for_thread()
         self.Y, self.X = Y, X
         self.keep_planes = keep_planes
+        self.inflight = max(1, int(inflight))
         self.labels = {}   # frame -> DeviceBuffer (int32 label map)
         self.planes = {}   # frame -> torch tensor (Y, X) float64 on this GPU
 
     def process_frame(self, t, stack_u16):
+        return self._process_with(self.pipe, t, stack_u16)
+
+    def process_frames(self, frames, frame_source):
+        """All of this rank's frames, `inflight` at a time: worker threads, each with its own HIP stream, workspaces and
+        FramePipeline (the library is re-entrant per thread), pull frames from a shared iterator -- one frame's host->device
+        upload overlaps the other frames' kernels, and the latency-bound watershed of one overlaps the projection of
+        another.  frame_source(t) is called from the worker threads."""
+        import threading
+        frames = list(frames)
+        if self.inflight <= 1 or len(frames) <= 1:
+            return {t: self.process_frame(t, frame_source(t)) for t in frames}
         from . import _lib
-        p = self.pipe
-        d_stack = p.upload_stack(stack_u16)
+        from .pipeline import FramePipeline
+        it, lock, out, errors = iter(frames), threading.Lock(), {}, []
+
+        def work():
+            try:
+                _lib.init(self.device)
+                pipe = FramePipeline(*self._shape, **self._kw)
+                while True:
+                    with lock:
+                        t = next(it, None)
+                    if t is None:
+                        return
+                    out[t] = self._process_with(pipe, t, frame_source(t))
+            except BaseException as e:      # a dead worker must fail the movie, not shorten it silently
+                errors.append(e)
+
+        threads = [threading.Thread(target=work) for _ in range(min(self.inflight, len(frames)))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+        return out
+
+    def _process_with(self, p, t, stack_u16):
+        from . import _lib
+        if hasattr(stack_u16, "data_ptr"):        # a (pinned) torch tensor: copied straight from its storage
+            nbytes = stack_u16.numel() * stack_u16.element_size()
+            d_stack = _lib.DeviceBuffer(nbytes)
+            _lib.check(p.lib.tip_memcpy_h2d(_lib.dptr(d_stack.ptr), _lib.dptr(stack_u16.data_ptr()), nbytes))
+        else:
+            d_stack = p.upload_stack(stack_u16)
         p.project(d_stack)
         p.segment(0)
         nbytes = self.Y * self.X * 4
@@ -216,7 +264,10 @@ def process_movie(n_frames, frame_source, backend, rank=0, world=1, dist=None, d
         drifts = np.zeros((n_frames, 2))
     drifts = np.array(drifts, dtype=np.float64)
     mine = list(range(rank, n_frames, world))
-    local = {t: backend.process_frame(t, frame_source(t)) for t in mine}
+    if hasattr(backend, "process_frames"):
+        local = backend.process_frames(mine, frame_source)        # several frames in flight on this rank's GPU
+    else:
+        local = {t: backend.process_frame(t, frame_source(t)) for t in mine}
     if estimate_drift:
         prev = exchange_planes(n_frames, mine, backend, rank, world, dist)
         for t in mine:

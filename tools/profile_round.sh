@@ -49,7 +49,9 @@ for n in sorted(acc, key=lambda k: -dur[k])[:25]:
     a = acc[n]
     busy = a.get("SQ_BUSY_CU_CYCLES", 0.0)
     out[n] = {"calls": calls[n], "total_ms": round(dur[n] / 1e6, 3), "SQ_VALU_MFMA_BUSY_CYCLES": a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
-              "SQ_BUSY_CU_CYCLES": busy, "mfma_busy_over_cu_busy": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy, 4) if busy else None}
+              "SQ_BUSY_CU_CYCLES": busy, "mfma_busy_over_cu_busy": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy, 4) if busy else None,
+              # the matrix pipe's busy cycles are counted per SIMD (4 per CU): fraction of the busy CUs' MFMA issue capacity
+              "mfma_pipe_busy_frac": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy / 4.0, 4) if busy else None}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print("wrote", sys.argv[2])
 PY
