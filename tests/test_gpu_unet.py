@@ -136,7 +136,8 @@ def test_unet_leg_at_headline_size():
 
 def test_fused_conv_epilogue_equals_torch_ops(monkeypatch):
     """bias -> ReLU -> BN scale/shift in one in-place HIP pass (tip_bias_relu_affine_f32_dev, torch's current stream)
-    is bit-identical to the torch expressions it replaces, and so is the whole network with either epilogue."""
+    is bit-identical to the torch expressions it replaces; the whole network agrees with either epilogue to float32
+    rounding (MIOpen's convolution kernels are not bit-reproducible from call to call, so no exact equality there)."""
     import torch
     from tissue_image_processing_amd import prediction_local as pl
     net = pl._UNet(2, torch.device("cuda", 0), dtype=torch.float32, seed=5)
@@ -154,4 +155,4 @@ def test_fused_conv_epilogue_equals_torch_ops(monkeypatch):
     fused = net.forward(inp)
     monkeypatch.setenv("TISSUE_HIP_UNET_TORCH_EPILOGUE", "1")
     plain = net.forward(inp)
-    assert torch.equal(fused, plain)
+    assert float((fused - plain).abs().max()) < 1e-5
