@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# MIOpen's default find mode benchmarks many solvers the first time it sees a convolution shape (minutes for the U-Net's
+# 2048^2 layers on a fresh box); the tests check results, not speed, so they take the heuristic pick.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
