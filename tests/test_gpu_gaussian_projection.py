@@ -213,6 +213,31 @@ def test_projection_fast_path_equals_generic_path(mods, monkeypatch):
         np.testing.assert_array_equal(p_fast, p_gen)
 
 
+def test_fused_mask_kernel_equals_separate_kernels(mods, monkeypatch):
+    """k_mask_wmax_fused (y pass + x pass of the blurred one-hot mask + weighted z-max in one kernel, the mask volume never
+    written) against the separate sparse kernels: bit-identical, with airyscan offset, three channels, a shifted second
+    mask, frames that are not multiples of the tile and a rough z-map (random planes: wide z ranges per tile)."""
+    _, sp, _ = mods
+    from tissue_image_processing_amd import synthetic
+    rng = np.random.default_rng(4)
+    cases = [(synthetic.make_stack(9, 200, 264, seed=1), dict(airyscan=False, atoh_shift=-1)),
+             (synthetic.make_stack(12, 77, 136, seed=2, channels=3, offset=10000), dict(airyscan=True, atoh_shift=0)),
+             (synthetic.make_stack(30, 130, 520, seed=3), dict(airyscan=False, atoh_shift=2)),
+             (rng.integers(0, 4000, (2, 16, 90, 300)).astype(np.uint16), dict(airyscan=False, atoh_shift=0))]
+    for st, kw in cases:
+        try:
+            monkeypatch.delenv("TIP_PROJECT_UNFUSED_MASK", raising=False)
+            p_f, z_f = sp.time_point_surface_projection(st, "CZYX", 0, z_map=True, **kw)
+            monkeypatch.setenv("TIP_PROJECT_UNFUSED_MASK", "1")
+            p_s, z_s = sp.time_point_surface_projection(st, "CZYX", 0, z_map=True, **kw)
+        except IndexError:
+            continue      # (a shifted plane fell off the stack: the reference's IndexError, both paths)
+        finally:
+            monkeypatch.delenv("TIP_PROJECT_UNFUSED_MASK", raising=False)
+        np.testing.assert_array_equal(z_f, z_s)
+        np.testing.assert_array_equal(p_f, p_s)
+
+
 def test_certified_argmax_equals_exact_score_path(mods, monkeypatch):
     """The fast float32 score passes + certification + exact fix-up give the same z-map as the exact float64 passes,
     including on data built to make neighbouring planes nearly tie."""

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_corr_long_f32(const float *__restrict__
 constexpr int FAST_SEG = 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int AXIS, int TO, int NW, int R, int VAR>
+template <int AXIS, int TO, int NW, int R, int VAR, int REM = 0>
 __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X,
                                                         TapsF taps)
 {
@@ -275,6 +275,24 @@ __global__ void __launch_bounds__(NW * 64) k_corr_long_fast(const float *__restr
                     // short partial sums (H <= FAST_SEG taps each): see the error bound above k_argmax_certify
 #pragma unroll
                     for (int j = 0; j < H; ++j) { tot[j] += acc[j]; acc[j] = f32x2{0.f, 0.f}; }
+                }
+                if constexpr (REM > 0) {   // radius % H == REM: the last REM taps (d = REM .. 1), one more short partial sum
+#pragma unroll
+                    for (int kk = 0; kk < REM; ++kk) {
+                        const int d = REM - kk;
+                        const float w = wl[r - d];
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc[j] = __builtin_elementwise_fma(L[j] + Rr[j], f32x2{w, w}, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < H - 1; ++j) L[j] = L[j + 1];
+#pragma unroll
+                        for (int j = H - 1; j > 0; --j) Rr[j] = Rr[j - 1];
+                        lds_cvf32 q = (lds_cvf32)ctr;
+                        L[H - 1] = f32x2{q[(H - d) * LS], q[(2 * H - d) * LS]};
+                        Rr[0] = f32x2{q[(d - 1) * LS], q[(H + d - 1) * LS]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < H; ++j) tot[j] += acc[j];
                 }
 #pragma unroll
                 for (int j = 0; j < H; ++j) { res[j] = tot[j].x; res[j + H] = tot[j].y; }

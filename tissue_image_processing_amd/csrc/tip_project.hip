@@ -375,6 +375,126 @@ __global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restri
                 if (x0 + k < X) proj[(long)c * P + (long)y * X + x0 + k] = (double)mx[c][k];
 }
 
+// ---- P7 y + x pass and P8 fused: the blurred one-hot mask never reaches HBM -----------------------------------------------
+// One block = FT_Y x FT_X outputs.  The chosen-plane map of the tile (+ 8-pixel halo, edges replicated) sits in LDS; plane
+// by plane the block computes the y pass of the tile's columns into an LDS buffer (exact scipy order, zero outside a
+// column's [zmin - 4, zmax + 4] exactly as the dense pass gives) and every thread finishes the x pass for its 8 outputs
+// from that buffer, multiplies with the raw stack and keeps the per-channel maximum -- the arithmetic of k_mask_y_sparse
+// + k_xpass_wmax_sparse, without writing the 503 MB mask volume and reading a third of it back.
+constexpr int FT_Y = 16, FT_X = 128, FT_W = FT_X + 2 * MASK_R, FT_H = FT_Y + 2 * MASK_R;
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_mask_wmax_fused(const float *__restrict__ table, const int32_t *__restrict__ zsel,
+                                                         const uint16_t *__restrict__ img, int C, int Zfull, int zlo, int Zs, int Y,
+                                                         int X, int airy, unsigned chan_mask, Taps taps, double *__restrict__ proj)
+{
+    extern __shared__ float sT[];                       // Zs * Zs: T[z * Zs + z0]
+    __shared__ unsigned char zs[FT_H][FT_W];            // chosen plane, rows y0-8 .. y0+FT_Y+7, columns x0-8 .. x0+FT_X+7
+    __shared__ unsigned char cmin[FT_Y][FT_W], cmax[FT_Y][FT_W];   // range of the 17-row window under every (row, column)
+    __shared__ __attribute__((aligned(16))) float ybuf[2][FT_Y][FT_W];
+    __shared__ int s_lo, s_hi;
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y;
+    const long P = (long)Y * X;
+    for (int i = t; i < Zs * Zs; i += 256) sT[i] = table[i];
+    for (int i = t; i < FT_H * FT_W; i += 256) {
+        const int r = i / FT_W, c = i - r * FT_W;
+        zs[r][c] = (unsigned char)zsel[(long)clampi(y0 - MASK_R + r, 0, Y - 1) * X + clampi(x0 - MASK_R + c, 0, X - 1)];
+    }
+    if (t == 0) { s_lo = Zs; s_hi = -1; }
+    __syncthreads();
+    int lo = Zs, hi = -1;
+    for (int i = t; i < FT_Y * FT_W; i += 256) {
+        const int r = i / FT_W, c = i - r * FT_W;
+        int a = zs[r][c], b = a;
+#pragma unroll
+        for (int k = 1; k < MASK_W; ++k) { const int v = zs[r + k][c]; a = min(a, v); b = max(b, v); }
+        cmin[r][c] = (unsigned char)a; cmax[r][c] = (unsigned char)b;
+        lo = min(lo, a); hi = max(hi, b);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); }
+    if ((t & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    const int zaB = max(s_lo - MASK_ZR, 0), zbB = min(s_hi + MASK_ZR, Zs - 1);
+    // this thread's outputs: row ty, columns cx .. cx+7 of the tile; their z range = the windows cx .. cx+23 of row ty
+    const int ty = t >> 4, cx = (t & 15) * 8;
+    const int gy = y0 + ty, gx = x0 + cx;
+    const bool live = gy < Y && gx < X;
+    int za = Zs, zb = -1;
+    if (live) {
+        for (int c = cx; c < cx + 8 + 2 * MASK_R; ++c) { za = min(za, (int)cmin[ty][c]); zb = max(zb, (int)cmax[ty][c]); }
+        za = max(za - MASK_ZR, 0); zb = min(zb + MASK_ZR, Zs - 1);
+    }
+    float mx[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx[c][k] = 0.f;
+    for (int z = zaB; z <= zbB; ++z) {
+        float(*yb)[FT_W] = ybuf[(z - zaB) & 1];
+        const float *Tz = sT + z * Zs;
+        for (int i = t; i < FT_Y * FT_W; i += 256) {     // y pass of plane z for the tile's columns
+            const int r = i / FT_W, c = i - r * FT_W;
+            float val = 0.f;
+            if (z >= (int)cmin[r][c] - MASK_ZR && z <= (int)cmax[r][c] + MASK_ZR) {
+                double tmp = (double)Tz[zs[r + MASK_R][c]] * taps.w[MASK_R];
+#pragma unroll
+                for (int d = MASK_R; d >= 1; --d)
+                    tmp += ((double)Tz[zs[r + MASK_R - d][c]] + (double)Tz[zs[r + MASK_R + d][c]]) * taps.w[MASK_R - d];
+                val = (float)tmp;
+            }
+            yb[r][c] = val;
+        }
+        __syncthreads();        // (the buffer of plane z-1 is free again only after the NEXT barrier: two buffers, one barrier per plane)
+        if (live && z >= za && z <= zb) {
+            float v[8 + 2 * MASK_R];
+#pragma unroll
+            for (int i = 0; i < (8 + 2 * MASK_R) / 4; ++i) {
+                const float4 f = *reinterpret_cast<const float4 *>(&yb[ty][cx + 4 * i]);
+                v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+            }
+            float m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double tmp = (double)v[k + MASK_R] * taps.w[MASK_R];
+#pragma unroll
+                for (int d = MASK_R; d >= 1; --d)
+                    tmp += ((double)v[k + MASK_R - d] + (double)v[k + MASK_R + d]) * taps.w[MASK_R - d];
+                m[k] = (float)tmp;
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c < C && ((chan_mask >> c) & 1u)) {
+                    const uint16_t *ip = img + ((long)c * Zfull + zlo + z) * P + (long)gy * X + gx;
+                    unsigned short pix[8];
+                    if (gx + 8 <= X && (X & 7) == 0) {
+                        const uint4 u = *reinterpret_cast<const uint4 *>(ip);
+                        pix[0] = u.x & 0xffff; pix[1] = u.x >> 16; pix[2] = u.y & 0xffff; pix[3] = u.y >> 16;
+                        pix[4] = u.z & 0xffff; pix[5] = u.z >> 16; pix[6] = u.w & 0xffff; pix[7] = u.w >> 16;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) pix[k] = gx + k < X ? ip[k] : 0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float val = (float)pix[k];
+                        if (airy) { val -= 10000.f; if (val < 0.f) val = 0.f; }
+                        const float pr = val * m[k];
+                        mx[c][k] = pr > mx[c][k] ? pr : mx[c][k];
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C && ((chan_mask >> c) & 1u))
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (gx + k < X) proj[(long)c * P + (long)gy * X + gx + k] = (double)mx[c][k];
+    }
+}
+
 // (waves per block) * 100 + (outputs per lane and group) of the fast sigma-30 passes; see k_corr_long_fast
 #ifndef FAST_CFG_Y
 #define FAST_CFG_Y 11616
@@ -383,13 +503,13 @@ __global__ void __launch_bounds__(256) k_xpass_wmax_sparse(const float *__restri
 #define FAST_CFG_X 11616
 #endif
 
-template <int AXIS, int NW, int R, int VAR>
+template <int AXIS, int NW, int R, int VAR, int REM = 0>
 static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
     const int r = t.n >> 1;
-    if (VAR != 0 && r % (R / 2)) return fail(TIP_ERR_ARG, "fast pass: radius %d is not a multiple of %d", r, R / 2);
+    if (VAR != 0 && r % (R / 2) != REM) return fail(TIP_ERR_ARG, "fast pass: radius %d mod %d is not %d", r, R / 2, REM);
     const size_t lds = (size_t)(256 + 2 * r) * (AXIS == 1 ? 64 : 65) * sizeof(float);
-    auto k = k_corr_long_fast<AXIS, 256, NW, R, VAR>;
+    auto k = k_corr_long_fast<AXIS, 256, NW, R, VAR, REM>;
     TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid = AXIS == 1 ? dim3(cdiv(X, 64), cdiv(Y, 256), Zs) : dim3(cdiv(Y, 64), cdiv(X, 256), Zs);
     TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(NW * 64), lds, in, out, Zs, Y, X, t);
@@ -399,10 +519,14 @@ static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, co
 template <int AXIS>
 static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
-    if (cfg / 10000 == 1 && ((t.n >> 1) % 8)) cfg -= 10000;   // the packed variant needs radius % H == 0
+    const int r = t.n >> 1;
+    if (cfg == 10832 && r % 16 != 0 && r % 16 != 8) cfg = 11616;   // 32 outputs per lane: radius % 16 must be 0 or 8
+    if (cfg / 10000 == 1 && cfg != 10832 && (r % 8)) cfg -= 10000;  // the packed variant needs radius % H == 0
     switch (cfg) {   // variant * 10000 + waves * 100 + outputs per lane
     case 1616: return launch_fast_cfg<AXIS, 16, 16, 0>(in, out, Zs, Y, X, t);
     case 11616: return launch_fast_cfg<AXIS, 16, 16, 1>(in, out, Zs, Y, X, t);
+    case 10832:   // 8 waves, 32 outputs per lane: half the LDS window reads per output, 2 waves per SIMD
+        return r % 16 == 0 ? launch_fast_cfg<AXIS, 8, 32, 1, 0>(in, out, Zs, Y, X, t) : launch_fast_cfg<AXIS, 8, 32, 1, 8>(in, out, Zs, Y, X, t);
     default: return fail(TIP_ERR_ARG, "unknown fast-pass configuration %d", cfg);
     }
 }
@@ -823,7 +947,10 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         const int32_t *sel = pass == 0 ? zsel : zsel_a;
         unsigned cm = atoh_shift == 0 ? all : (pass == 0 ? (1u << ref_ch) : (all & ~(1u << ref_ch)));
         if (!cm) continue;
-        if (fast && Zs <= 64 && (long)Zs * Y < 2147483647L) {
+        if (fast && Zs <= 64 && !getenv("TIP_PROJECT_UNFUSED_MASK")) {
+            TIP_LAUNCH("mask_wmax_fused", (k_mask_wmax_fused<8>), dim3(cdiv(X, FT_X), cdiv(Y, FT_Y)), dim3(256),
+                       (size_t)Zs * Zs * sizeof(float), (const float *)table, sel, czyx, C, Z, zlo, Zs, Y, X, airyscan, cm, k2, proj);
+        } else if (fast && Zs <= 64 && (long)Zs * Y < 2147483647L) {
             TIP_LAUNCH("mask_y_sparse", (k_mask_y_sparse<2>), dim3(cdiv(X, 256), cdiv(Y, 2 * MASK_W)), dim3(256),
                        (size_t)Zs * Zs * sizeof(float), (const float *)table, sel, Zs, Y, X, k2, A, zrange);
             TIP_LAUNCH("xpass_wmax_sparse", (k_xpass_wmax_sparse<8>), dim3(cdiv(cdiv(X, 8), 256), Y), dim3(256), 0, (const float *)A,
