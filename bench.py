@@ -36,6 +36,7 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
         "corr_z_u16clip": V * 2 + V * 4,
         "corr_long_y": 2 * V * 4, "corr_long_x": 2 * V * 4,
         "score_fast_y": 2 * V * 4, "score_fast_x": 2 * V * 4,
+        "preblur_fused": V * 2 + V * 4,   # the four short passes in one kernel: uint16 stack in, one float32 volume out
         "zpass_u16clip_x4": V * 2 + V * 4, "zpass_f32_x4": 2 * V * 4, "ypass_slide_r4": 2 * V * 4, "xpass_slide_r4": 2 * V * 4,
         "argmax_certify": V * 4 + P * 4, "mask_y_sparse": P * 4 + V * 4, "xpass_wmax_sparse": V * 4 + C * V * 2 + C * P * 8,
         # fused P6-P8: read the z-map and (logically) the stack once, write the projection; the blurred mask stays in LDS
@@ -57,7 +58,7 @@ PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in
     "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
     "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",
     "regionprops": "k_regionprops", "hist_u16": "k_hist_u16", "mask_y_sparse": "k_mask_y_sparse",
-    "xpass_wmax_sparse": "k_xpass_wmax_sparse", "argmax_certify": "k_argmax_certify", "mask_wmax_fused": "k_mask_wmax_fused",
+    "xpass_wmax_sparse": "k_xpass_wmax_sparse", "argmax_certify": "k_argmax_certify", "mask_wmax_fused": "k_mask_wmax_fused", "preblur_fused": "k_preblur_fused",
 }
 
 

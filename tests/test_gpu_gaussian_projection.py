@@ -238,6 +238,29 @@ def test_fused_mask_kernel_equals_separate_kernels(mods, monkeypatch):
         np.testing.assert_array_equal(p_f, p_s)
 
 
+def test_fused_preblur_kernel_equals_separate_kernels(mods, monkeypatch):
+    """k_preblur_fused (uint16 -> z 0.5 -> y 1 -> x 1 -> z 0.5 in one kernel) against the four separate register-sliding
+    kernels: identical z-maps and projections, incl. few planes (Z = 1, 2, 3), ragged frames, the airyscan offset."""
+    _, sp, _ = mods
+    from tissue_image_processing_amd import synthetic
+    rng = np.random.default_rng(6)
+    cases = [(synthetic.make_stack(9, 200, 264, seed=1), dict(airyscan=False)),
+             (synthetic.make_stack(12, 77, 136, seed=2, channels=3, offset=10000), dict(airyscan=True)),
+             (synthetic.make_stack(30, 130, 520, seed=3), dict(airyscan=False, atoh_shift=-2)),
+             (rng.integers(0, 4000, (2, 1, 40, 132)).astype(np.uint16), dict(airyscan=False)),
+             (rng.integers(0, 4000, (2, 2, 33, 260)).astype(np.uint16), dict(airyscan=False)),
+             (rng.integers(0, 4000, (1, 3, 64, 128)).astype(np.uint16), dict(airyscan=False)),
+             (rng.integers(0, 60000, (2, 5, 31, 12)).astype(np.uint16), dict(airyscan=True))]
+    for st, kw in cases:
+        monkeypatch.delenv("TIP_PROJECT_UNFUSED_PREBLUR", raising=False)
+        p_f, z_f = sp.time_point_surface_projection(st, "CZYX", 0, z_map=True, **kw)
+        monkeypatch.setenv("TIP_PROJECT_UNFUSED_PREBLUR", "1")
+        p_s, z_s = sp.time_point_surface_projection(st, "CZYX", 0, z_map=True, **kw)
+        monkeypatch.delenv("TIP_PROJECT_UNFUSED_PREBLUR", raising=False)
+        np.testing.assert_array_equal(z_f, z_s)
+        np.testing.assert_array_equal(p_f, p_s)
+
+
 def test_certified_argmax_equals_exact_score_path(mods, monkeypatch):
     """The fast float32 score passes + certification + exact fix-up give the same z-map as the exact float64 passes,
     including on data built to make neighbouring planes nearly tie."""

@@ -1,0 +1,142 @@
+// tip_preblur.h -- the projection's four short passes in ONE kernel (sp.py:26-37 and the z pass of sp.py:55):
+//
+//     uint16 stack --(offset, clip)--> z pass sigma 0.5 --> y pass sigma 1 --> x pass sigma 1 --> z pass sigma 0.5 --> float32
+//
+// i.e. blur_image(ch, (0.5, 1, 1)) followed by the z pass of blur_image(., (0.5, 30, 30)).  As four kernels these move
+// 5.2 GB through HBM for 0.75 GB of compulsory traffic (read the uint16 stack, write one float32 volume); here a block
+// walks a (PB_Y x PB_X)-pixel tile (+ 4-pixel halo) through all planes:
+//   * every thread owns a few pixels of the padded tile and slides their raw values through a 5-plane register window
+//     (first z pass, exactly k_zpass_r2_x4's arithmetic), writing the plane to LDS;
+//   * y pass and x pass run on that LDS plane (same tap order as k_ypass_slide / k_xpass_slide, each rounded to float32);
+//   * the x-pass outputs of the last 5 planes stay in registers and the second z pass streams the result to HBM.
+// Every pass accumulates in float64 in scipy's order and rounds to float32 exactly where the separate kernels do, so the
+// output is bit-identical to them (tests compare the two paths).  The intermediate volume (the (0.5, 1, 1)-blurred
+// channel itself) is not produced: callers that need it (bin_size > 1) use the separate kernels.
+#pragma once
+#include "tip_slide.h"
+
+namespace tip {
+
+constexpr int PB_Y = 32, PB_X = 128, PB_H = 4, PB_T = 1024, PB_O = 4;   // 1024 threads: 6 padded-tile pixels and 4 outputs each
+// (measured: 512 threads with 8 outputs each 0.87 ms, two 512-thread blocks per CU on 16-row tiles 0.58 ms, this 0.57 ms;
+//  the four separate kernels 0.78 ms)
+struct ShortTaps { double w[8]; };    // the first radius + 1 taps of a Taps (two full Taps would not fit the 4 KB kernel-argument segment)
+constexpr int PB_WY = PB_Y + 2 * PB_H, PB_WX = PB_X + 2 * PB_H;       // padded tile: 40 x 136
+constexpr int PB_OWN = (PB_WY * PB_WX + PB_T - 1) / PB_T;             // padded-tile pixels per thread (11)
+
+__global__ void __launch_bounds__(PB_T) k_preblur_fused(const uint16_t *__restrict__ src, int airy, const float *__restrict__ clip_p95,
+                                                        const int *__restrict__ clip_has, float *__restrict__ out, int Z, int Y, int X,
+                                                        ShortTaps k05, ShortTaps k1)
+{
+    __shared__ __attribute__((aligned(16))) float p1[PB_WY][PB_WX];    // plane after the first z pass (padded tile)
+    __shared__ __attribute__((aligned(16))) float yb[PB_Y][PB_WX];     // after the y pass
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * PB_X, y0 = blockIdx.y * PB_Y;
+    const long P = (long)Y * X;
+    const bool has = *clip_has != 0;
+    const float cp = *clip_p95;
+    // this thread's pixels of the padded tile (edges replicated: clamped coordinates)
+    int off[PB_OWN];     // (a plane has fewer than 2^31 pixels)
+#pragma unroll
+    for (int k = 0; k < PB_OWN; ++k) {
+        const int i = t + k * PB_T;
+        const int r = i / PB_WX, c = i - r * PB_WX;
+        off[k] = i < PB_WY * PB_WX ? clampi(y0 - PB_H + r, 0, Y - 1) * X + clampi(x0 - PB_H + c, 0, X - 1) : -1;
+    }
+    auto raw = [&](int z, int k) -> float {
+        float v = (float)src[(long)z * P + (long)off[k]];
+        if (airy) { v -= 10000.f; if (v < 0.f) v = 0.f; }
+        if (has && v > cp) v = cp;
+        return v;
+    };
+    // first z pass: raw window (planes z-2 .. z+2 of the plane being produced), 'nearest' at both ends
+    float w[PB_OWN][5];      // (float32: windows in double cost registers and with them occupancy -- measured 1.8x slower)
+#pragma unroll
+    for (int k = 0; k < PB_OWN; ++k) {
+        if (off[k] < 0) continue;
+        const float a = raw(0, k);
+        w[k][0] = w[k][1] = w[k][2] = a;
+        w[k][3] = raw(min(1, Z - 1), k);
+        w[k][4] = raw(min(2, Z - 1), k);
+    }
+    // second z pass: window [A(zo-2) .. A(zo+2)] of x-pass output planes for this thread's 8 output pixels (row oy, columns
+    // ox .. ox+7), 'nearest' at both ends exactly like the first one: starts as [A0, A0, A0, A1, A2], then slides
+    const int oy = t / (PB_X / PB_O), ox = (t % (PB_X / PB_O)) * PB_O;
+    float ring[5][PB_O], last[PB_O];
+    for (int zp = 0; zp < Z + 2; ++zp) {      // zp < Z: plane zp goes through the in-plane passes; output plane zp - 2 follows
+        if (zp < Z) {
+#pragma unroll
+            for (int k = 0; k < PB_OWN; ++k) {
+                if (off[k] < 0) continue;
+                const int i = t + k * PB_T;
+                double tmp = (double)w[k][2] * k05.w[2];
+                tmp += ((double)w[k][0] + (double)w[k][4]) * k05.w[0];
+                tmp += ((double)w[k][1] + (double)w[k][3]) * k05.w[1];
+                (&p1[0][0])[i] = (float)tmp;
+                w[k][0] = w[k][1]; w[k][1] = w[k][2]; w[k][2] = w[k][3]; w[k][3] = w[k][4];
+                w[k][4] = raw(min(zp + 3, Z - 1), k);
+            }
+        }
+        __syncthreads();
+        if (zp < Z) {
+            // y pass: work item = (column, 4-row segment); 136 columns x (PB_Y / 4) segments
+            for (int item = t; item < PB_WX * (PB_Y / 4); item += PB_T) {
+                const int yc = item % PB_WX, yr = (item / PB_WX) * 4;
+                double win[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) win[i] = (double)p1[yr + i][yc];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    double tmp = win[o + 4] * k1.w[4];
+#pragma unroll
+                    for (int d = 4; d >= 1; --d) tmp += (win[o + 4 - d] + win[o + 4 + d]) * k1.w[4 - d];
+                    yb[yr + o][yc] = (float)tmp;
+                }
+            }
+        }
+        __syncthreads();
+        if (zp < Z) {                                                           // x pass: PB_O outputs from PB_O + 8 inputs
+            float v[PB_O + 8];
+#pragma unroll
+            for (int i = 0; i < (PB_O + 8) / 4; ++i) {
+                const float4 f = *reinterpret_cast<const float4 *>(&yb[oy][ox + 4 * i]);
+                v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+            }
+#pragma unroll
+            for (int k = 0; k < PB_O; ++k) {
+                double tmp = (double)v[k + 4] * k1.w[4];
+#pragma unroll
+                for (int d = 4; d >= 1; --d) tmp += ((double)v[k + 4 - d] + (double)v[k + 4 + d]) * k1.w[4 - d];
+                last[k] = (float)tmp;
+            }
+        }   // (zp >= Z: `last` keeps the last plane: the window's far end is replicated)
+#pragma unroll
+        for (int k = 0; k < PB_O; ++k) {
+            if (zp == 0) ring[0][k] = ring[1][k] = ring[2][k] = last[k];
+            else if (zp == 1) ring[3][k] = last[k];
+            else if (zp == 2) ring[4][k] = last[k];
+            else { ring[0][k] = ring[1][k]; ring[1][k] = ring[2][k]; ring[2][k] = ring[3][k]; ring[3][k] = ring[4][k]; ring[4][k] = last[k]; }
+        }
+        const int zo = zp - 2;
+        if (zo >= 0 && y0 + oy < Y && x0 + ox < X) {
+            float o[PB_O];
+#pragma unroll
+            for (int k = 0; k < PB_O; ++k) {
+                double tmp = (double)ring[2][k] * k05.w[2];
+                tmp += ((double)ring[0][k] + (double)ring[4][k]) * k05.w[0];
+                tmp += ((double)ring[1][k] + (double)ring[3][k]) * k05.w[1];
+                o[k] = (float)tmp;
+            }
+            float *dst = out + (long)zo * P + (long)(y0 + oy) * X + x0 + ox;
+            if (x0 + ox + PB_O <= X && (X & 3) == 0) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PB_O; ++k)
+                    if (x0 + ox + k < X) dst[k] = o[k];
+            }
+        }
+    }
+}
+
+}  // namespace tip

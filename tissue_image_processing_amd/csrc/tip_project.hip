@@ -8,6 +8,7 @@
 //   P6/P7 one-hot mask + Gaussian (1,2,2) (sp.py:62-71)             z pass = ZxZ table, y pass from the z-map,
 //   P8  per-channel max_z(image * mask) -> float64 (sp.py:72-81)    x pass fused with the weighted z-max
 #include "tip_slide.h"
+#include "tip_preblur.h"
 #include <cstdlib>
 
 namespace tip {
@@ -871,7 +872,14 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         if ((r2 = correlate1d_dev(B_, A_, 0, Zs, Y, X, 2, k1, 0))) return r2;
         return correlate1d_dev(A_, B_, 0, Zs, Y, X, 0, k05, 0);
     };
-    if ((rc = short_blur(ref, clip, A, B))) return rc;
+    // bin_size == 1 only needs the z-passed blur (B): the four short passes run as one kernel (tip_preblur.h)
+    const bool fused_pre = fast && bin == 1 && !getenv("TIP_PROJECT_UNFUSED_PREBLUR");
+    if (fused_pre) {
+        ShortTaps s05, s1;
+        for (int i = 0; i < 8; ++i) { s05.w[i] = i < 3 ? k05.w[i] : 0.0; s1.w[i] = i < 5 ? k1.w[i] : 0.0; }
+        TIP_LAUNCH("preblur_fused", k_preblur_fused, dim3(cdiv(X, PB_X), cdiv(Y, PB_Y)), dim3(PB_T), 0, ref, airyscan,
+                   (const float *)&clip->p95, (const int *)&clip->has, B, Zs, Y, X, s05, s1);
+    } else if ((rc = short_blur(ref, clip, A, B))) return rc;
     if (bin > 1) {
         // P4' (sp.py:39-65): score on bin x bin blocks, resized back to the frame for the argmax
         const int Yb = cdiv(Y, bin), Xb = cdiv(X, bin);
