@@ -9,6 +9,8 @@
 //   P8  per-channel max_z(image * mask) -> float64 (sp.py:72-81)    x pass fused with the weighted z-max
 #include "tip_slide.h"
 #include "tip_preblur.h"
+#include "tip_corr_mfma.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace tip {
@@ -517,10 +519,33 @@ static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, co
     return TIP_OK;
 }
 
+// the same pass on the matrix cores (tip_corr_mfma.h)
+template <int AXIS>
+static int launch_mfma(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
+{
+    const int r = t.n >> 1;
+    if (r < 1 || r > 127 || (16 + r) % MF_SEG) return fail(TIP_ERR_ARG, "mfma pass: radius %d (16 + r must be a multiple of %d)", r, MF_SEG);
+    const int npos = MF_TO + 2 * r;
+    const size_t lds = AXIS == 1 ? (size_t)npos * MF_LN * sizeof(float)
+                                 : (size_t)MF_LN * (npos + 1 + (npos & 1)) * sizeof(float);
+    auto k = k_corr_long_mfma<AXIS>;
+    TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles_pos = cdiv(AXIS == 1 ? Y : X, MF_TO), tiles_ln = cdiv(AXIS == 1 ? X : Y, MF_LN);
+    const int ntiles = tiles_pos * tiles_ln * Zs;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx().device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int blocks = std::min(ntiles, 2 * cus);       // persistent blocks, two per CU (LDS: 64 KB each)
+    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, dim3(blocks), dim3(MF_NW * 64), lds, in, out, Zs, Y, X, t, ntiles,
+               tiles_pos, tiles_ln);
+    return TIP_OK;
+}
+
 template <int AXIS>
 static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
     const int r = t.n >> 1;
+    if (cfg == 3) return launch_mfma<AXIS>(in, out, Zs, Y, X, t);
     if (cfg == 10832 && r % 16 != 0 && r % 16 != 8) cfg = 11616;   // 32 outputs per lane: radius % 16 must be 0 or 8
     if (cfg / 10000 == 1 && cfg != 10832 && (r % 8)) cfg -= 10000;  // the packed variant needs radius % H == 0
     switch (cfg) {   // variant * 10000 + waves * 100 + outputs per lane
