@@ -54,7 +54,8 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
 
 
 PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r*_pmc_traffic.json
-    "ws_tiles": "k_ws_tiles<16, 64, 3, 6>", "score_fast_y": "k_corr_long_fast<1", "score_fast_x": "k_corr_long_fast<2",
+    "ws_tiles": "k_ws_tiles<16, 64, 3, 6>", "score_fast_y": ("k_corr_long_mfma<1", "k_corr_long_mfma2<1", "k_corr_long_fast<1"),
+    "score_fast_x": ("k_corr_long_mfma<2", "k_corr_long_mfma2<2", "k_corr_long_fast<2"),
     "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
     "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",
     "regionprops": "k_regionprops", "hist_u16": "k_hist_u16", "mask_y_sparse": "k_mask_y_sparse",
@@ -71,9 +72,11 @@ def pmc_traffic(kernel):
     if not key or not paths:
         return None
     path = paths[-1]   # the latest committed set
-    for name, rec in json.load(open(path)).items():
-        if key in name:
-            return (rec["fetch_MB_per_call_x2corrected"] + rec["write_MB_per_call"]) * 1e6
+    recs = json.load(open(path))
+    for k in (key if isinstance(key, tuple) else (key,)):      # (alternatives: whichever variant of the kernel the profiled build ran)
+        for name, rec in recs.items():
+            if k in name:
+                return (rec["fetch_MB_per_call_x2corrected"] + rec["write_MB_per_call"]) * 1e6
     return None
 
 
@@ -475,15 +478,20 @@ def main():
                             % leg["iso_steps"])
         roof_timed = roofline_of(merge(leg["timed"]), args.steps)
         kernels = kernel_table(leg["iso"], leg["iso_steps"])
-        # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are FP32-VALU bound, not HBM bound: 120 tap pairs x
-        # (add + fma) + 1 multiply per output = 361 flop per voxel and pass; peak = MI355X FP32 vector (packed FMA) rate
+        # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are bound by the FP32 matrix pipe, not by HBM: the
+        # banded-Toeplitz MFMA tiles issue 2 * (32 + 2 * 120) flop per voxel and pass (241 of the 272 products of an output
+        # are non-zero taps; "achieved" counts the issued flops, "useful" the 2 * 241 of a direct correlation); the dense
+        # FP32 MFMA peak equals the FP32 vector peak (256 flop / clk / CU)
         valu = {}
         for kname in ("score_fast_y", "score_fast_x"):
             if kname in leg["iso"] and leg["iso"][kname][0]:
                 cnt_k, ms_k = leg["iso"][kname]
-                tf = Z * Y * X * 361.0 / (ms_k / cnt_k / 1e3) / 1e12
-                valu[kname] = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": tf / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
+                sec = ms_k / cnt_k / 1e3
+                tf = Z * Y * X * 544.0 / sec / 1e12
+                valu[kname] = {"bound": "mfma_fp32", "achieved": tf, "useful": Z * Y * X * 482.0 / sec / 1e12,
+                               "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+                               "avg_launch_ms": ms_k / cnt_k,
+                               "note": "default build (TIP_FAST_CFG unset): matrix-core kernels; with a VALU configuration the issued-flop figure does not apply"}
         out = {
             "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

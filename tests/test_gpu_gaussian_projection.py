@@ -311,19 +311,23 @@ def test_projection_headline_frame_vs_oracle(mods):
     np.testing.assert_array_equal(proj, rproj)
 
 
-def test_scalar_fast_pass_variant_gives_the_same_zmap(mods, monkeypatch):
-    """The scalar fast-pass variant (used when the score radius is not a multiple of 8) is selected here through the
-    tuning hook; certification makes the z-map independent of which fast variant produced the approximate score."""
+def test_every_fast_pass_variant_gives_the_same_zmap(mods, monkeypatch):
+    """The approximate sigma-30 score comes from the matrix-core kernels by default (k_corr_long_mfma for y,
+    k_corr_long_mfma2 for x); the tuning hook selects the other variants (both MFMA kernels on both axes, the packed and
+    the scalar VALU kernels).  Certification makes the z-map independent of which variant produced the score: all equal
+    the all-exact float64 path, on a frame whose extents are not multiples of the tiles (ragged edge tiles, more tiles
+    than persistent blocks)."""
     _, sp, _ = mods
     from tissue_image_processing_amd import synthetic
-    st = synthetic.make_stack(12, 512, 768, seed=77)
-    proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
-    monkeypatch.setenv("TIP_FAST_CFG", "1616,1616")
-    proj_s, zmap_s = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
-    monkeypatch.delenv("TIP_FAST_CFG")
-    monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
-    proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
-    np.testing.assert_array_equal(zmap, zmap_e)
-    np.testing.assert_array_equal(zmap_s, zmap_e)
-    np.testing.assert_array_equal(proj, proj_e)
-    np.testing.assert_array_equal(proj_s, proj_e)
+    for shape, seed in [((12, 515, 777), 77), ((30, 1100, 1300), 78)]:
+        st = synthetic.make_stack(*shape, seed=seed)
+        monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
+        proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+        monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE")
+        for cfg in (None, "3,3", "4,4", "4,3", "11616,11616", "1616,1616"):
+            if cfg:
+                monkeypatch.setenv("TIP_FAST_CFG", cfg)
+            proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+            monkeypatch.delenv("TIP_FAST_CFG", raising=False)
+            assert int((zmap != zmap_e).sum()) == 0, cfg
+            np.testing.assert_array_equal(proj, proj_e)

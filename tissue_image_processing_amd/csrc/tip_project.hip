@@ -9,7 +9,7 @@
 //   P8  per-channel max_z(image * mask) -> float64 (sp.py:72-81)    x pass fused with the weighted z-max
 #include "tip_slide.h"
 #include "tip_preblur.h"
-#include "tip_corr_mfma.h"
+#include "tip_corr_mfma2.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -498,13 +498,27 @@ __global__ void __launch_bounds__(256) k_mask_wmax_fused(const float *__restrict
     }
 }
 
-// (waves per block) * 100 + (outputs per lane and group) of the fast sigma-30 passes; see k_corr_long_fast
+// Configuration of the fast sigma-30 passes: 3 / 4 = the matrix-core kernels (tip_corr_mfma.h / tip_corr_mfma2.h), else
+// variant * 10000 + (waves per block) * 100 + (outputs per lane and group) of the VALU kernel k_corr_long_fast.
+// Measured on the 2048 x 2048 x 30 frame, one frame in flight, y / x pass: VALU 0.79 / 0.81 ms, 3: 0.67 / 0.69 ms,
+// 4: 0.76 / 0.69 ms; whole classical pipeline 155 / 166.6 / 169.4 frames/s for (VALU, VALU) / (3, 3) / (3, 4), and
+// 242.7 / 249.8 / 252.2 with four frames in flight.
 #ifndef FAST_CFG_Y
-#define FAST_CFG_Y 11616
+#define FAST_CFG_Y 3
 #endif
 #ifndef FAST_CFG_X
-#define FAST_CFG_X 11616
+#define FAST_CFG_X 4
 #endif
+
+static int cu_count()
+{
+    static int cus = 0;          // (same device model on every GPU of a node; a benign race writes the same value)
+    if (!cus) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, ctx().device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
 
 template <int AXIS, int NW, int R, int VAR, int REM = 0>
 static int launch_fast_cfg(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
@@ -532,12 +546,35 @@ static int launch_mfma(const float *in, float *out, int Zs, int Y, int X, const 
     TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles_pos = cdiv(AXIS == 1 ? Y : X, MF_TO), tiles_ln = cdiv(AXIS == 1 ? X : Y, MF_LN);
     const int ntiles = tiles_pos * tiles_ln * Zs;
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx().device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int cus = cu_count();
     const int blocks = std::min(ntiles, 2 * cus);       // persistent blocks, two per CU (LDS: 64 KB each)
     TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, dim3(blocks), dim3(MF_NW * 64), lds, in, out, Zs, Y, X, t, ntiles,
                tiles_pos, tiles_ln);
+    return TIP_OK;
+}
+
+// ... with asynchronous global -> LDS copies and one double-buffered persistent block per CU (tip_corr_mfma2.h)
+template <int AXIS>
+static int launch_mfma2(const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
+{
+    const int r = t.n >> 1;
+    if (r < 8 || r > 120 || r % MF_SEG) return fail(TIP_ERR_ARG, "mfma pass: radius %d (a multiple of %d in [8, 120])", r, MF_SEG);
+    const int npos = MF_TO + 2 * r;
+    const int pitch = 514;                                // AXIS 2: 512 copied positions per line; 2 (mod 64): the 32 lines x 2
+                                                          // positions of an operand read hit 64 different banks
+    const int bufsz = AXIS == 1 ? npos * MF_LN : MF_LN * pitch;
+    const size_t lds = ((size_t)2 * bufsz + 2 * 127 + 64 + 64) * sizeof(float);   // + padded kernel + sink
+    if (lds > 160 * 1024) return fail(TIP_ERR_ARG, "mfma pass: tile buffers exceed the LDS");
+    auto k = k_corr_long_mfma2<AXIS>;
+    TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles_pos = cdiv(AXIS == 1 ? Y : X, MF_TO), tiles_ln = cdiv(AXIS == 1 ? X : Y, MF_LN);
+    const long nt = (long)tiles_pos * tiles_ln * Zs;
+    if (nt > 0x7fffffffL - 4096) return fail(TIP_ERR_ARG, "mfma pass: too many tiles");
+    const int ntiles = (int)nt;
+    const int cus = cu_count();
+    const int blocks = std::min(ntiles, cus);             // persistent blocks, one per CU (two 62 KB tile buffers each)
+    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, dim3(blocks), dim3(MF_NW * 64), lds, in, out, Zs, Y, X, t, ntiles,
+               tiles_pos, tiles_ln, pitch, bufsz);
     return TIP_OK;
 }
 
@@ -545,7 +582,9 @@ template <int AXIS>
 static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
 {
     const int r = t.n >> 1;
+    if ((cfg == 3 || cfg == 4) && (r < 8 || r > 120 || r % MF_SEG)) cfg = 11616;   // the MFMA tiles need radius % 8 == 0 (sigma 30: 120)
     if (cfg == 3) return launch_mfma<AXIS>(in, out, Zs, Y, X, t);
+    if (cfg == 4) return launch_mfma2<AXIS>(in, out, Zs, Y, X, t);
     if (cfg == 10832 && r % 16 != 0 && r % 16 != 8) cfg = 11616;   // 32 outputs per lane: radius % 16 must be 0 or 8
     if (cfg / 10000 == 1 && cfg != 10832 && (r % 8)) cfg -= 10000;  // the packed variant needs radius % H == 0
     switch (cfg) {   // variant * 10000 + waves * 100 + outputs per lane
