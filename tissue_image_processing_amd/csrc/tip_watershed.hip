@@ -58,6 +58,11 @@ struct WsInfo {           // device-resident scalars
                                      // same-address atomics per launch serialise in L2 (host adds them up)
     unsigned long long fb_v, fb_k;   // fallback reduction
     unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
+    // endgame results (own words: the tile launches that follow the endgame in the same submission must not clobber them)
+    int end_part[64];                // serial commits, spread like changed_part
+    int end_oversize, end_unfinished;   // cells of components larger than END_CAP / components whose replay hit the step limit
+    int ncomp, ncells;               // endgame: components of undecided pixels and their cells (k_end_offsets)
+    int und_total, front_total;      // k_ws_tile_totals: undecided pixels / those of them that touch a labelled pixel
 };
 
 // Both reductions: 4 independent loads per thread and trip, one atomic per BLOCK (thousands of same-address 64-bit
@@ -359,16 +364,19 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     __shared__ unsigned short slist[2][WT * WT];
     __shared__ int s_n[2], s_any, s_und, s_chg, s_front;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
-    if (first == 2 && tile_und[tile] == 0) return;  // wide pass: every tile that still has undecided pixels
+    // (every block writes its changed_cur word, also when it has nothing to do: no memset between launches)
+    if (first == 2 && tile_und[tile] == 0) { if (threadIdx.x == 0) changed_cur[tile] = 0; return; }  // wide pass: every tile that still has undecided pixels
     if (!first) {
-        if (tile_und[tile] == 0) return;
-        bool act = false;
-        for (int j = -1; j <= 1; ++j)
-            for (int i = -1; i <= 1; ++i) {
-                const int yy = ty + j, xx = tx + i;
-                if (yy >= 0 && yy < tilesY && xx >= 0 && xx < tilesX) act |= changed_prev[yy * tilesX + xx] != 0;
-            }
-        if (!act) return;
+        bool act = tile_und[tile] != 0;
+        if (act) {
+            act = false;
+            for (int j = -1; j <= 1; ++j)
+                for (int i = -1; i <= 1; ++i) {
+                    const int yy = ty + j, xx = tx + i;
+                    if (yy >= 0 && yy < tilesY && xx >= 0 && xx < tilesX) act |= changed_prev[yy * tilesX + xx] != 0;
+                }
+        }
+        if (!act) { if (threadIdx.x == 0) changed_cur[tile] = 0; return; }
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
     {   // window load: all state loads of the thread in flight together, then all value loads (the value a labelled
@@ -580,6 +588,7 @@ __global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long 
 // each one is finished by ONE wave running the serial rule -- commit the component's smallest pop time, repeat -- on an
 // LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / global-minimum fallback.
 constexpr int END_CAP = 512;
+constexpr int END_GRID = 4096;     // blocks of the endgame launch: they stride over the device-side component count
 constexpr int WS_EARLY_BURST = 1;   // the first endgame runs after this many tile bursts (the first has 10 launches), without waiting for a stall
 constexpr int WS_END_STEPS = 32;    // serial commits per component and endgame: clears the stuck seeds, the rest is tile work
 
@@ -633,7 +642,8 @@ __global__ void __launch_bounds__(256) k_end_scatter(const unsigned long long *_
 __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                     const int *__restrict__ roots, const int *__restrict__ cnt,
                                                     const int *__restrict__ off, const int *__restrict__ cells,
-                                                    const int *__restrict__ slot, int max_steps, WsInfo *info)
+                                                    const int *__restrict__ slot, const int *__restrict__ ncomp_d, int max_steps,
+                                                    WsInfo *info)
 {
     constexpr int EPL = END_CAP / 64;       // cells per lane
     constexpr unsigned long long NONE = ~0ULL;
@@ -644,9 +654,12 @@ __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v
     __shared__ int cnb[4][END_CAP];         // >= 0 local slot, -1 nothing (outside / line), -2 external labelled cell
     __shared__ double ev[4][END_CAP];       // external labelled neighbour: pop-time value
     __shared__ int etr[4][END_CAP], elab[4][END_CAP];
-    const int r = roots[blockIdx.x];
+    // (the grid is launched without knowing the number of components on the host: blocks stride over the device-side count)
+    const int ncomp = *ncomp_d;
+    for (int comp = blockIdx.x; comp < ncomp; comp += gridDim.x) {
+    const int r = roots[comp];
     const int m = cnt[r];
-    if (m > END_CAP) { if (threadIdx.x == 0) atomicAdd(&info->undecided, m); return; }
+    if (m > END_CAP) { if (threadIdx.x == 0) atomicAdd(&info->end_oversize, m); continue; }
     const int base = off[r];
     const int lane = threadIdx.x;
     // candidate keys: hi = encoded pop-time value (NONE: not a candidate), lo = reference pixel << 32 | own pixel
@@ -745,8 +758,10 @@ __global__ void __launch_bounds__(64) k_end_resolve(const double *__restrict__ v
     }
     for (int k = lane; k < m; k += 64)
         if (clab[k] != 0) st[cgi[k]] = pack_st(clab[k], ctr[k]);
-    if (lane == 0 && committed) atomicAdd(&info->changed_part[blockIdx.x & 63], committed);
-    if (lane == 0 && committed == max_steps) atomicAdd(&info->unfinished, 1);   // (may have been finished exactly: harmless)
+    if (lane == 0 && committed) atomicAdd(&info->end_part[comp & 63], committed);
+    if (lane == 0 && committed == max_steps) atomicAdd(&info->end_unfinished, 1);   // (may have been finished exactly: harmless)
+    __syncthreads();   // the LDS copy is reused by the block's next component
+    }
 }
 
 // ---- mode B: two-valued image (pl.py:194 floods a {0, 255} boundary image) --------------------------------------------
@@ -979,9 +994,41 @@ __global__ void k_ws_info_init(WsInfo *info)
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
+    info->end_oversize = 0; info->end_unfinished = 0; info->ncomp = 0; info->ncells = 0; info->und_total = 0; info->front_total = 0;
+    for (int q = 0; q < 64; ++q) info->end_part[q] = 0;
+}
+__global__ void k_ws_changed_reset(WsInfo *info)
+{
+    info->changed = 0;
+    for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
+}
+__global__ void k_ws_end_reset(WsInfo *info)
+{
+    info->end_oversize = 0; info->end_unfinished = 0; info->ncomp = 0; info->ncells = 0;
+    for (int q = 0; q < 64; ++q) info->end_part[q] = 0;
+}
+// totals over the tiles' bookkeeping (a tile that sat a launch out keeps its last count, which is still true: only the
+// tile itself decides its interior -- after an endgame or a fallback commit every tile is woken and recounts)
+__global__ void __launch_bounds__(256) k_ws_tile_totals(const int *__restrict__ tile_und, const int *__restrict__ tile_front, int ntiles,
+                                                        WsInfo *info)
+{
+    __shared__ int su, sf;
+    if (threadIdx.x == 0) { su = 0; sf = 0; }
+    __syncthreads();
+    int u = 0, f = 0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        const int a = tile_und[t];
+        u += a;
+        if (a) f += tile_front[t];
+    }
+    for (int d = 32; d >= 1; d >>= 1) { u += __shfl_xor(u, d, 64); f += __shfl_xor(f, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (u | f)) { atomicAdd(&su, u); atomicAdd(&sf, f); }
+    __syncthreads();
+    if (threadIdx.x == 0 && (su | sf)) { atomicAdd(&info->und_total, su); atomicAdd(&info->front_total, sf); }
 }
 __global__ void k_ws_iter_reset(WsInfo *info)
 {
+    info->und_total = 0; info->front_total = 0;
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
@@ -1117,52 +1164,92 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         // fallback machinery
         const int dbg = getenv("TIP_WS_DEBUG") ? 1 : 0;
         const bool no_endgame = getenv("TIP_WS_NO_ENDGAME") != nullptr, no_wide = getenv("TIP_WS_NO_WIDE") != nullptr;
-        int *cursor = nullptr, *cellsbuf = nullptr, *slot = nullptr, *roots = nullptr, *ncomp_d = nullptr;   // endgame workspaces
+        int *cursor = nullptr, *cellsbuf = nullptr, *slot = nullptr, *roots = nullptr;   // endgame workspaces
+        // one launch of the everyday tiles (activity words ping-pong by launch parity; every block writes its word)
+        auto tile_launch = [&](int it) -> int {
+            unsigned char *prev = chg + (size_t)(it & 1) * ntiles, *cur = chg + (size_t)((it + 1) & 1) * ntiles;
+            TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y, X,
+                       tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, it == 0 ? 1 : 0, 4096, dbg, info);
+            return TIP_OK;
+        };
+        // the endgame, submitted without a host round trip: components of undecided pixels, their cell lists, and one wave
+        // per component replaying the serial rule (the grid strides over the device-side component count); results in
+        // info->end_*; every tile is woken afterwards
+        auto endgame_submit = [&]() -> int {
+            SameU su{st};
+            int rc2 = uf_components(su, parent, Y, X);
+            if (rc2) return rc2;
+            TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));      // cnt
+            TIP_LAUNCH("ws_end_count", k_end_count, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
+                       (const int *)parent, flag, isroot, n);
+            if (!cursor) {   // taken from the pool once per call
+                cursor = ws.get<int>(n); cellsbuf = ws.get<int>(n); slot = ws.get<int>(n); roots = ws.get<int>(n);
+            }
+            if (!cursor || !cellsbuf || !slot || !roots) return TIP_ERR_NOMEM;
+            TIP_LAUNCH("ws_end_reset", k_ws_end_reset, dim3(1), dim3(1), 0, info);
+            TIP_LAUNCH("ws_end_offsets", k_end_offsets, dim3(cdiv(n, 256)), dim3(256), 0, (const int *)flag, (const int *)isroot,
+                       rank /* start of every component's cells in cellsbuf */, roots, &info->ncomp, n);
+            TIP_HIP(hipMemsetAsync(cursor, 0, n * sizeof(int), s));
+            TIP_LAUNCH("ws_end_scatter", k_end_scatter, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
+                       (const int *)parent, (const int *)rank, cursor, cellsbuf, slot, n);
+            TIP_LAUNCH("ws_end_resolve", k_end_resolve, dim3(END_GRID), dim3(64), 0, img, st, Y, X, (const int *)roots,
+                       (const int *)flag, (const int *)rank, (const int *)cellsbuf, (const int *)slot, (const int *)&info->ncomp,
+                       WS_END_STEPS, info);
+            TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+            return TIP_OK;
+        };
         for (;; ++iter) {
             TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-            // tile launches go out in bursts with ONE host check per burst (a launch whose tiles are all inactive costs
-            // ~15 us, a host round trip ~50 us): 10 launches first (the bulk); after the early endgame its dependents need
-            // ~8 more launches (measured), sent as one burst; then 2 at a time
-            const int burst = wide ? 1 : (burst_no == 0 ? 10 : (burst_no == post_end_burst ? 8 : 2));
-            burst_no++;
-            for (int rep = 0; rep < burst; ++rep) {
-                if (rep) ++iter;
-                unsigned char *prev = chg + (size_t)(iter & 1) * ntiles, *cur = chg + (size_t)((iter + 1) & 1) * ntiles;
-                TIP_HIP(hipMemsetAsync(cur, 0, ntiles, s));
-                if (!wide)
-                    TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y,
-                               X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, iter == 0 ? 1 : 0, 4096, dbg, info);
-                else {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
-                    TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img,
-                               st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, wtile_und + wntiles, 1, 4096, dbg, info);
-                    TIP_HIP(hipMemsetAsync(cur, 1, ntiles, s));
+            // The opening is ONE submission with one host check at its end (a host round trip idles the GPU for ~50 us):
+            // 10 tile launches (the bulk), the early endgame -- what is left then are a few thousand pixels in long
+            // dependency chains that would cost one latency-bound launch per tile border crossed, replayed serially per
+            // component instead -- and the 8 launches its dependents need (measured on 2048^2 frames: endgame after 10
+            // launches with 32 serial steps per component 2.9 ms per frame; after 6 launches 4.0 ms, after 12 3.05 ms,
+            // 512 steps 3.7 ms, no early endgame 3.6 ms).  Later: tile launches in bursts of 2 with a check per burst.
+            const bool opening = burst_no == 0 && !no_endgame && !dbg;
+            if (opening) {
+                for (int rep = 0; rep < 10; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
+                if ((rc = endgame_submit())) return rc;
+                TIP_LAUNCH("ws_changed_reset", k_ws_changed_reset, dim3(1), dim3(1), 0, info);
+                for (int rep = 10; rep < 18; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
+                iter += 17;
+                burst_no = 2;
+                early_done = true;
+                endgames++;
+            } else {
+                // (debug / no-endgame runs open with the plain bursts: 10 launches, then 8 after the early endgame)
+                const int burst = wide ? 1 : (burst_no == 0 ? 10 : (burst_no == post_end_burst ? 8 : 2));
+                burst_no++;
+                for (int rep = 0; rep < burst; ++rep) {
+                    if (rep) ++iter;
+                    if (!wide) {
+                        if ((rc = tile_launch(iter))) return rc;
+                    } else {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
+                        TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img,
+                                   st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, wtile_und + wntiles, 1, 4096, dbg, info);
+                        TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles, 1, ntiles, s));
+                    }
                 }
             }
+            TIP_LAUNCH("ws_tile_totals", k_ws_tile_totals, dim3(16), dim3(256), 0, (const int *)tile_und, (const int *)(tile_und + ntiles),
+                       ntiles, info);
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
             if (dbg)
-                fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d\n", iter, wide ? "wide" : "fast",
-                        h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed);
-            // The first two bursts do the bulk; what is left then are a few thousand pixels in long dependency chains
-            // that would cost one (latency-bound) launch per tile border crossed: replay them serially per component
-            // right away instead of waiting for the tile rounds to stall.
-            // (measured on 2048^2 frames: after 10 launches with 32 serial steps per component 2.9 ms per frame; after 6
-            // launches 4.0 ms, after 12 3.05 ms, 512 steps 3.7 ms, no early endgame 3.6 ms)
+                fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d undecided %d\n", iter, wide ? "wide" : "fast",
+                        h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed, h.und_total);
+            if (opening) {
+                if (h.und_total == 0) break;
+                if (h.end_oversize == 0 && h.end_unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
+                if (h.changed > 0) continue;                                // the endgame's dependents are still moving
+                // else: quiescent already -- the stall handling below
+            }
             const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !no_endgame;
             if (h.changed > 0 && !early_endgame) { wide = false; continue; }
             const bool quiescent = h.changed == 0;
-            long und_total = 1, front_total = 1;
-            if (quiescent || !early_endgame) {   // (the early endgame runs regardless: it finds "nothing left" itself)
-                und_total = 0; front_total = 0;
-                std::vector<int> hu((size_t)2 * ntiles);
-                TIP_HIP(hipMemcpyAsync(hu.data(), tile_und, (size_t)2 * ntiles * 4, hipMemcpyDeviceToHost, s));
-                TIP_HIP(hipStreamSynchronize(s));
-                for (int t = 0; t < ntiles; ++t) {
-                    und_total += hu[t];
-                    if (hu[t]) front_total += hu[ntiles + t];
-                }
-            }
+            // (after a wide pass the fine tiles' counts are stale -- too large, never too small)
+            const long und_total = h.und_total, front_total = h.front_total;
             if (und_total == 0) break;
             // quiescent and no undecided pixel touches a labelled one: what is left is enclosed by lines and stays 0.
             // (After a wide pass the fine tiles' counts are stale, so this shortcut only applies to the fine rounds.)
@@ -1171,45 +1258,22 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 // serial rule on every connected component of undecided pixels that fits one wave's LDS copy
                 if (!early_done) post_end_burst = burst_no;
                 early_done = true;
-                SameU su{st};
-                if ((rc = uf_components(su, parent, Y, X))) return rc;
-                TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));      // cnt
-                TIP_LAUNCH("ws_end_count", k_end_count, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
-                           (const int *)parent, flag, isroot, n);
-                int *off = rank;                                            // start of every component's cells in cellsbuf
-                if (!cursor) {   // taken from the pool once per call (lazily: many frames never get here twice)
-                    cursor = ws.get<int>(n); cellsbuf = ws.get<int>(n); slot = ws.get<int>(n); roots = ws.get<int>(n);
-                    ncomp_d = ws.get<int>(2);                               // [0] components, [1] cells
-                }
-                if (!cursor || !cellsbuf || !slot || !roots || !ncomp_d) return TIP_ERR_NOMEM;
-                TIP_HIP(hipMemsetAsync(ncomp_d, 0, 2 * sizeof(int), s));
-                TIP_LAUNCH("ws_end_offsets", k_end_offsets, dim3(cdiv(n, 256)), dim3(256), 0, (const int *)flag, (const int *)isroot,
-                           off, roots, ncomp_d, n);
-                TIP_HIP(hipMemsetAsync(cursor, 0, n * sizeof(int), s));
-                TIP_LAUNCH("ws_end_scatter", k_end_scatter, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st,
-                           (const int *)parent, (const int *)off, cursor, cellsbuf, slot, n);
-                int ncomp = 0;
-                TIP_HIP(hipMemcpyAsync(&ncomp, ncomp_d, sizeof(int), hipMemcpyDeviceToHost, s));
-                TIP_HIP(hipStreamSynchronize(s));
-                TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-                if (ncomp > 0)
-                    TIP_LAUNCH("ws_end_resolve", k_end_resolve, dim3(ncomp), dim3(64), 0, img, st, Y, X, (const int *)roots,
-                               (const int *)flag, (const int *)off, (const int *)cellsbuf, (const int *)slot, WS_END_STEPS, info);
+                if ((rc = endgame_submit())) return rc;
                 TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
                 TIP_HIP(hipStreamSynchronize(s));
-                for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
+                int end_changed = 0;
+                for (int q = 0; q < 64; ++q) end_changed += h.end_part[q];
                 if (dbg)
-                    fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d, unfinished %d\n", ncomp, h.changed, h.undecided, h.unfinished);
+                    fprintf(stderr, "ws endgame: %d components, committed %d, oversize cells %d, unfinished %d\n", h.ncomp, end_changed,
+                            h.end_oversize, h.end_unfinished);
                 endgames++;
-                if (h.undecided == 0 && h.unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
-                if (h.changed > 0 || !quiescent) {   // oversize components remain: back to the tile rounds for them
-                    TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
+                if (h.end_oversize == 0 && h.end_unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
+                if (end_changed > 0 || !quiescent) {   // oversize components remain: back to the tile rounds for them
                     wide = false;
                     continue;
                 }
                 // only oversize components remain: wide pass / global-minimum fallback machinery
                 wide_after_endgame = true;
-                TIP_HIP(hipMemsetAsync(chg, 1, (size_t)2 * ntiles, s));
                 wide = true;
                 continue;
             }
