@@ -186,6 +186,14 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 // ~10 px long on smooth landscapes) is tried before the global-minimum fallback.
 constexpr int WT_FAST = 16, WTH_FAST = 64, WH_FAST = 3, WK_FAST = 6;
 constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
+// Everyday tile flavour (index into tile_launch's switch) and the opening (tile launches before / after the early endgame).
+// Measured on the 2048^2 headline frame, tile kernel time per frame / launches / single-frame rate:
+//   0  16x16, halo 3, interior only, every waiting cell re-evaluated each round   1.65 ms / 20 / 172.7 frames/s  (opening 10,8)
+//   5  same with the event-driven work list                                       1.45 ms / 18 / 179.4          (8,6)
+//   6  16x16, halo 4, 3-cell evaluated margin, event-driven                        1.49 ms / 14 / 181.6          (6,6)
+//   4  as 6 without the event-driven list 1.58 ms (6,6); margins 5 / 7: 1.83 / 2.67 ms; 32x32 tiles (64, 128, 256 threads):
+//   2.2 - 2.5 ms -- a launch costs in proportion to the cells it evaluates, and fewer resident tiles hide less latency
+constexpr int WS_TILE_DEFAULT = 6, WS_OPEN_A = 6, WS_OPEN_B = 6;
 constexpr int LINE_LAB = -1;
 // tile-local marker "undecided and already on the work list": label 0 with a non-zero reference field (never leaves LDS)
 constexpr unsigned long long ST_LISTED = 1ULL << 32;
@@ -352,16 +360,23 @@ __device__ __forceinline__ Decision ws_decide(const TileView &tv, int c, int gc,
 // One block = one 32x32 tile (+ halo) iterated to its local fixed point.  Work list: only undecided cells that touch a
 // labelled cell (the frontier) are evaluated each round; a cell that gets labelled wakes its undecided interior
 // neighbours.  Cheap rule while the tile progresses, pocket certificates for one round when it stalls.
-template <int WT, int WS_THREADS, int WH, int WK>
+// WM > 0: the tile also evaluates a margin of WM cells around its interior (redundantly with its neighbours -- a certified
+// decision is the same whoever takes it) and stores every decision straight to global memory: dependency chains that
+// zig-zag across a tile border no longer cost one launch per crossing.
+// EV = 1: event-driven work list.  A cell that has to wait LEAVES the list and comes back when one of its neighbours is
+// decided (label or line) -- instead of being re-evaluated every round until its lower neighbours are through.
+template <int WT, int WS_THREADS, int WH, int WK, int WM = 0, int EV = 0>
 __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
                                                   unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
                                                   int *__restrict__ tile_front, int first, int max_rounds, int dbg, WsInfo *info)
 {
     constexpr int WL = WT + 2 * WH;
+    constexpr int WE = WT + 2 * WM, E0 = WH - WM, E1 = WL - E0;    // evaluated region: window rows / columns [E0, E1)
+    static_assert(WM >= 0 && WM < WH, "the outermost window ring is read-only");
     __shared__ WCell cells[WL * WL];
     __shared__ unsigned short svis[WS_THREADS * WK];
-    __shared__ unsigned short slist[2][WT * WT];
+    __shared__ unsigned short slist[2][WE * WE];
     __shared__ int s_n[2], s_any, s_und, s_chg, s_front;
     const int tile = blockIdx.x, ty = tile / tilesX, tx = tile % tilesX;
     // (every block writes its changed_cur word, also when it has nothing to do: no memset between launches)
@@ -410,16 +425,27 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     __syncthreads();
     const int g00 = gy0 * X + gx0;
     TileView tv{cells, svis + threadIdx.x * WK, WK, WL, g00, X};
-    // initial frontier: undecided interior cells next to a labelled cell
-    unsigned was_und = 0;   // bit k: own interior cell k was undecided when the window was loaded
+    // initial frontier: undecided cells of the evaluated region next to a labelled cell
+    unsigned was_und = 0;   // (WM == 0) bit k: own interior cell k was undecided when the window was loaded
+    if (WM == 0) {
 #pragma unroll
-    for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
-        const int p = threadIdx.x + k * WS_THREADS;
-        const int c = (p / WT + WH) * WL + (p % WT + WH);
-        if (st_lab(cells[c].st) == 0) {
-            was_und |= 1u << k;
-            if (st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0) {
-                cells[c].st = ST_LISTED;
+        for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
+            const int p = threadIdx.x + k * WS_THREADS;
+            const int c = (p / WT + WH) * WL + (p % WT + WH);
+            if (st_lab(cells[c].st) == 0) {
+                was_und |= 1u << k;
+                if (st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0) {
+                    cells[c].st = ST_LISTED;
+                    slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
+                }
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < WE * WE; p += WS_THREADS) {
+            const int c = (p / WE + E0) * WL + (p % WE + E0);
+            if (st_lab(cells[c].st) == 0 &&
+                (st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0)) {
+                cells[c].st = ST_LISTED;      // (still label 0 for the threads that scan its neighbours)
                 slist[0][atomicAdd(&s_n[0], 1)] = (unsigned short)c;
             }
         }
@@ -427,59 +453,118 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     __syncthreads();
     int cur = 0, my_evals = 0, my_rounds = 0;
     bool certs = false;
-    for (int round = 0; round < max_rounds; ++round) {
-        const int n = s_n[cur];
-        if (n == 0) break;
-        my_rounds++;
-        if (threadIdx.x == 0) { s_n[cur ^ 1] = 0; s_any = 0; }
-        __syncthreads();
-        // The list is worked off in chunks of one entry per thread, each chunk committed before the next is evaluated
-        // (decisions are certified on the states they read, so committing earlier is just a finer round).  One inlined
-        // copy of the flood rule instead of four keeps the kernel small -- it is branchy scalar-heavy code and used to
-        // overflow the instruction cache -- and almost every round has a single chunk anyway.
-#pragma unroll 1
-        for (int base = 0; base < n; base += WS_THREADS) {
-            const int i = base + threadIdx.x;
-            int c = -1;
-            Decision dec{0, 0, 0.0};
-            if (i < n) {
-                const int c0 = slist[cur][i];
-                if (st_lab(cells[c0].st) == 0) { my_evals++; c = c0; dec = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
-                // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
+    if (EV) {
+        bool certs_done = false;
+        for (int round = 0; round < max_rounds; ++round) {
+            int n = s_n[cur];
+            if (n == 0) {
+                // the list ran dry.  A tile that got nowhere at all tries one round with pocket certificates on its frontier
+                // (they cost ~40 plain rounds; a tile that moved is re-run next launch anyway, with its neighbours' news)
+                if (certs_done || s_chg > 0) break;
+                __syncthreads();
+                for (int p = threadIdx.x; p < WE * WE; p += WS_THREADS) {
+                    const int c = (p / WE + E0) * WL + (p % WE + E0);
+                    if (cells[c].st == 0ULL &&
+                        (st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0)) {
+                        cells[c].st = ST_LISTED;
+                        slist[cur][atomicAdd(&s_n[cur], 1)] = (unsigned short)c;
+                    }
+                }
+                __syncthreads();
+                certs = true; certs_done = true;
+                n = s_n[cur];
+                if (n == 0) break;
             }
-            __syncthreads();  // every read of this chunk is done
-            if (c >= 0) {
-                if (dec.lab == 0) {  // still waiting: stays on the frontier
-                    slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
-                } else {
+            my_rounds++;
+            if (threadIdx.x == 0) s_n[cur ^ 1] = 0;
+            __syncthreads();
+#pragma unroll 1
+            for (int base = 0; base < n; base += WS_THREADS) {
+                const int i = base + threadIdx.x;
+                int c = -1;
+                Decision dec{0, 0, 0.0};
+                if (i < n) {
+                    c = slist[cur][i];         // (listed cells are undecided: a cell enters the list once per stay)
+                    my_evals++;
+                    dec = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs);
+                }
+                __syncthreads();  // every read of this chunk is done
+                if (c >= 0 && dec.lab == 0) cells[c].st = 0ULL;   // waits: off the list until a neighbour is decided
+                __syncthreads();  // (the drops first: a neighbour decided in this very chunk must be able to wake the cell)
+                if (c >= 0 && dec.lab != 0) {
                     cells[c].st = pack_st(dec.lab, dec.ti); cells[c].v = dec.tv;
-                    s_any = 1;
+                    if (WM > 0) st[g00 + (c / WL) * X + c % WL] = pack_st(dec.lab, dec.ti);   // (an undecided cell lies inside the image)
                     atomicAdd(&s_chg, 1);
-                    if (dec.lab > 0) {
-                        const int cy = c / WL, cx = c - cy * WL;   // c is interior: a neighbour is interior unless c is on that edge
+                    const int cy = c / WL, cx = c - cy * WL;   // c is evaluated: a neighbour is too unless c is on that edge of the region
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
-                            const bool inside = k == 0 ? cy > WH : (k == 1 ? cx > WH : (k == 2 ? cx < WH + WT - 1 : cy < WH + WT - 1));
-                            if (inside && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
-                                slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+                        const bool inside = k == 0 ? cy > E0 : (k == 1 ? cx > E0 : (k == 2 ? cx < E1 - 1 : cy < E1 - 1));
+                        if (inside && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
+                            slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                    }
+                }
+                __syncthreads();
+            }
+            cur ^= 1;
+            certs = false;
+        }
+    } else {
+        for (int round = 0; round < max_rounds; ++round) {
+            const int n = s_n[cur];
+            if (n == 0) break;
+            my_rounds++;
+            if (threadIdx.x == 0) { s_n[cur ^ 1] = 0; s_any = 0; }
+            __syncthreads();
+            // The list is worked off in chunks of one entry per thread, each chunk committed before the next is evaluated
+            // (decisions are certified on the states they read, so committing earlier is just a finer round).  One inlined
+            // copy of the flood rule instead of four keeps the kernel small -- it is branchy scalar-heavy code and used to
+            // overflow the instruction cache -- and almost every round has a single chunk anyway.
+    #pragma unroll 1
+            for (int base = 0; base < n; base += WS_THREADS) {
+                const int i = base + threadIdx.x;
+                int c = -1;
+                Decision dec{0, 0, 0.0};
+                if (i < n) {
+                    const int c0 = slist[cur][i];
+                    if (st_lab(cells[c0].st) == 0) { my_evals++; c = c0; dec = ws_decide(tv, c, g00 + (c / WL) * X + c % WL, certs); }
+                    // else: decided meanwhile (pushed by a neighbour in the round it was decided itself)
+                }
+                __syncthreads();  // every read of this chunk is done
+                if (c >= 0) {
+                    if (dec.lab == 0) {  // still waiting: stays on the frontier
+                        slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)c;
+                    } else {
+                        cells[c].st = pack_st(dec.lab, dec.ti); cells[c].v = dec.tv;
+                        if (WM > 0) st[g00 + (c / WL) * X + c % WL] = pack_st(dec.lab, dec.ti);   // (an undecided cell lies inside the image)
+                        s_any = 1;
+                        atomicAdd(&s_chg, 1);
+                        if (dec.lab > 0) {
+                            const int cy = c / WL, cx = c - cy * WL;   // c is evaluated: a neighbour is too unless c is on that edge of the region
+    #pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int q = k == 0 ? c - WL : (k == 1 ? c - 1 : (k == 2 ? c + 1 : c + WL));
+                                const bool inside = k == 0 ? cy > E0 : (k == 1 ? cx > E0 : (k == 2 ? cx < E1 - 1 : cy < E1 - 1));
+                                if (inside && atomicCAS(&cells[q].st, 0ULL, ST_LISTED) == 0ULL)
+                                    slist[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = (unsigned short)q;
+                            }
                         }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
+            cur ^= 1;
+            // every wave reads the round's flags before thread 0 may reset them at the top of the next round (blocks of
+            // more than one wave: without the barrier the waves could take different branches here)
+            const int any = s_any, chg = s_chg;
+            if (WS_THREADS > 64) __syncthreads();
+            if (any) { certs = false; continue; }
+            if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
+            // local stall.  Pocket certificates cost ~40 plain rounds, and a tile that has just moved is re-run next launch
+            // anyway (with its neighbours' news): only a tile that got nowhere at all tries them.
+            if (chg > 0) break;
+            certs = true;
         }
-        cur ^= 1;
-        // every wave reads the round's flags before thread 0 may reset them at the top of the next round (blocks of
-        // more than one wave: without the barrier the waves could take different branches here)
-        const int any = s_any, chg = s_chg;
-        if (WS_THREADS > 64) __syncthreads();
-        if (any) { certs = false; continue; }
-        if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
-        // local stall.  Pocket certificates cost ~40 plain rounds, and a tile that has just moved is re-run next launch
-        // anyway (with its neighbours' news): only a tile that got nowhere at all tries them.
-        if (chg > 0) break;
-        certs = true;
     }
     __syncthreads();
     // und: undecided cells left; front: those of them that touch a labelled cell.  When no tile changed any more and
@@ -487,14 +572,14 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     int und = 0, front = 0;
 #pragma unroll
     for (int k = 0; k < WT * WT / WS_THREADS; ++k) {
-        if (!((was_und >> k) & 1u)) continue;   // decided before this launch (cells outside the image are LINE)
+        if (WM == 0 && !((was_und >> k) & 1u)) continue;   // decided before this launch (cells outside the image are LINE)
         const int p = threadIdx.x + k * WS_THREADS;
         const int c = (p / WT + WH) * WL + (p % WT + WH);
         const unsigned long long sc = cells[c].st;
         if (st_lab(sc) == 0) {
             und++;
             front += st_lab(cells[c - WL].st) > 0 || st_lab(cells[c - 1].st) > 0 || st_lab(cells[c + 1].st) > 0 || st_lab(cells[c + WL].st) > 0;
-        } else {
+        } else if (WM == 0) {
             st[(ty * WT + p / WT) * X + tx * WT + p % WT] = sc;   // only this tile writes its interior
         }
     }
@@ -1145,7 +1230,14 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         TIP_HIP(hipStreamSynchronize(s));
         if (h.unfinished != 0) return fail(TIP_ERR_HIP, "watershed: a generation of the two-valued flood did not resolve");
     } else if (h.n_markers > 0) {
-        const int tilesX = cdiv(X, WT_FAST), tilesY = cdiv(Y, WT_FAST), ntiles = tilesX * tilesY;
+        // everyday tile flavour (tuning hook TIP_WS_TILE): interior edge, halo, evaluated margin
+        int variant = WS_TILE_DEFAULT, open_a = WS_OPEN_A, open_b = WS_OPEN_B;
+        if (const char *e = getenv("TIP_WS_TILE")) variant = atoi(e);
+        if (const char *e = getenv("TIP_WS_OPEN")) sscanf(e, "%d,%d", &open_a, &open_b);
+        if (variant < 0 || variant > 11 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
+            return fail(TIP_ERR_ARG, "watershed: bad TIP_WS_TILE / TIP_WS_OPEN");
+        const int WTv = variant == 3 || variant >= 8 ? 32 : WT_FAST;
+        const int tilesX = cdiv(X, WTv), tilesY = cdiv(Y, WTv), ntiles = tilesX * tilesY;
         const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
         unsigned char *wchg = ws.get<unsigned char>((size_t)2 * wntiles);
         int *wtile_und = ws.get<int>((size_t)2 * wntiles);
@@ -1168,8 +1260,22 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         // one launch of the everyday tiles (activity words ping-pong by launch parity; every block writes its word)
         auto tile_launch = [&](int it) -> int {
             unsigned char *prev = chg + (size_t)(it & 1) * ntiles, *cur = chg + (size_t)((it + 1) & 1) * ntiles;
-            TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, img, st, Y, X,
-                       tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, it == 0 ? 1 : 0, 4096, dbg, info);
+#define WS_TILE_ARGS img, st, Y, X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, it == 0 ? 1 : 0, 4096, dbg, info
+            switch (variant) {
+            case 0: TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, WS_TILE_ARGS); break;
+            case 1: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 2: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 8, 6, 7>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 3: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7>), dim3(ntiles), dim3(256), 0, WS_TILE_ARGS); break;
+            case 4: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 5: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 6: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 7: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 8: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7, 1>), dim3(ntiles), dim3(256), 0, WS_TILE_ARGS); break;
+            case 9: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 10: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 128, 3, 6, 0, 1>), dim3(ntiles), dim3(128), 0, WS_TILE_ARGS); break;
+            default: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            }
+#undef WS_TILE_ARGS
             return TIP_OK;
         };
         // the endgame, submitted without a host round trip: components of undecided pixels, their cell lists, and one wave
@@ -1208,11 +1314,11 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // 512 steps 3.7 ms, no early endgame 3.6 ms).  Later: tile launches in bursts of 2 with a check per burst.
             const bool opening = burst_no == 0 && !no_endgame && !dbg;
             if (opening) {
-                for (int rep = 0; rep < 10; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
+                for (int rep = 0; rep < open_a; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
                 if ((rc = endgame_submit())) return rc;
                 TIP_LAUNCH("ws_changed_reset", k_ws_changed_reset, dim3(1), dim3(1), 0, info);
-                for (int rep = 10; rep < 18; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
-                iter += 17;
+                for (int rep = open_a; rep < open_a + open_b; ++rep) if ((rc = tile_launch(iter + rep))) return rc;
+                iter += open_a + open_b - 1;
                 burst_no = 2;
                 early_done = true;
                 endgames++;
@@ -1292,7 +1398,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             // wake the tile of the committed pixel (its 3x3 neighbourhood follows through the activity rule)
             {
                 const int pi = (int)(unsigned)(h.fb_k & 0xffffffffULL);
-                const int t = (pi / X / WT_FAST) * tilesX + (pi % X) / WT_FAST;
+                const int t = (pi / X / WTv) * tilesX + (pi % X) / WTv;
                 TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles + t, 1, 1, s));
             }
         }
