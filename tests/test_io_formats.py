@@ -1,0 +1,128 @@
+"""CPU: the host I/O around the GPU path -- TIFF writer / reader, image sources, the chunk iterator's block order,
+concatenate_time_points (golden from the reference), the .seg archive layout."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tiff_round_trip_and_foreign_layouts(tmp_path):
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    rng = np.random.default_rng(1)
+    for dtype, axes, shape in ((np.uint16, "TCZYX", (2, 3, 4, 5, 6)), (np.uint8, "YX", (7, 9)), (np.float32, "CYX", (2, 8, 8)),
+                               (np.int32, "ZYX", (3, 4, 5))):
+        a = (rng.random(shape) * 200).astype(dtype)
+        p = str(tmp_path / "a.tif")
+        bim.save_tiff(p, a, axes=axes)
+        img, ax, sh, meta = bim.read_tiff(p)
+        assert ax == axes and sh == shape and img.dtype == dtype and meta is None
+        np.testing.assert_array_equal(img, a)
+    # uint16 normalisation on save (bim.py:183-188): round(img / max * 65535)
+    f = rng.random((2, 6, 6)) * 3.0
+    bim.save_tiff(str(tmp_path / "n.tif"), f, axes="CYX", data_type="uint16")
+    img, _, _, _ = bim.read_tiff(str(tmp_path / "n.tif"))
+    np.testing.assert_array_equal(img, np.round(f / f.max() * 65535).astype(np.uint16))
+    # a big-endian ImageJ hyperstack with two strips per page, written by hand
+    pages = (rng.random((6, 4, 5)) * 60000).astype(">u2")
+    desc = b"ImageJ=1.53f\nimages=6\nchannels=2\nframes=3\nhyperstack=true\n\0"
+    blob = bytearray(struct.pack(">2sHI", b"MM", 42, 8))
+    off = 8
+    for k in range(6):
+        ent = [(256, 3, 1, 5 << 16), (257, 3, 1, 4 << 16), (258, 3, 1, 16 << 16), (259, 3, 1, 1 << 16), (277, 3, 1, 1 << 16)]
+        extra = desc if k == 0 else b""
+        n_ent = len(ent) + 2 + (1 if extra else 0)
+        ifd_size = 2 + 12 * n_ent + 4
+        strips_at = off + ifd_size              # two LONG offsets + two LONG counts
+        extra_at = strips_at + 16
+        data_at = extra_at + len(extra)
+        ent += [(273, 4, 2, strips_at), (279, 4, 2, strips_at + 8)]
+        if extra:
+            ent.append((270, 2, len(extra), extra_at))
+        ent.sort()
+        nxt = data_at + 40 if k < 5 else 0
+        blob += struct.pack(">H", len(ent))
+        for tag, typ, cnt, val in ent:
+            blob += struct.pack(">HHII", tag, typ, cnt, val)
+        blob += struct.pack(">I", nxt)
+        blob += struct.pack(">4I", data_at, data_at + 20, 20, 20)
+        blob += extra + pages[k].tobytes()
+        off = nxt
+    p = str(tmp_path / "ij.tif")
+    open(p, "wb").write(bytes(blob))
+    img, ax, sh, meta = bim.read_tiff(p)
+    assert ax == "TCYX" and sh == (3, 2, 4, 5) and meta["channels"] == "2"
+    np.testing.assert_array_equal(img, pages.astype(np.uint16).reshape(3, 2, 4, 5))
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"not a tiff at all")
+        bim.read_tiff(p)
+
+
+def test_image_sources_and_chunk_order(tmp_path):
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    a = np.arange(2 * 3 * 4 * 5 * 6, dtype=np.uint16).reshape(2, 3, 4, 5, 6)
+    np.save(str(tmp_path / "a.npy"), a)
+    bim.save_tiff(str(tmp_path / "a.tif"), a, axes="TCZYX")
+    for src in (a, str(tmp_path / "a.npy"), str(tmp_path / "a.tif"), [a, a[:1]]):
+        d = bim.get_image_dimensions(src)
+        assert (d.T, d.C, d.Z, d.Y, d.X) == (2, 3, 4, 5, 6)
+        blocks = list(bim.read_image_in_chunks(src, dx=4, dy=3, dt=1))
+        assert [b.shape for b in blocks[:4]] == [(1, 3, 4, 3, 4), (1, 3, 4, 3, 2), (1, 3, 4, 2, 4), (1, 3, 4, 2, 2)]   # x fastest, then y
+        np.testing.assert_array_equal(blocks[5], a[1:2, :, :, 0:3, 4:6])
+    assert bim.get_image_dimensions([a, a[:1]], series=1).T == 1
+    assert tuple(bim.get_image_dimensions(a[0, 0])) == (1, 1, 4, 5, 6)          # lower-rank arrays: trailing axes of TCZYX
+    out = np.zeros((2, 3, 1, 5, 6))
+    got = list(bim.read_image_in_chunks(a, dt=1, dx=3, apply_function=lambda ch, k: ch.max(axis=2) * k, output=out, k=2.0))
+    assert len(got) == 4 and got[0].shape == (1, 3, 5, 3)
+    np.testing.assert_array_equal(out[:, :, 0], a.max(axis=2) * 2.0)
+    assert list(bim.read_image_in_chunks(a, apply_function=lambda ch: ch)) == []      # no output array: nothing is yielded (bim.py:121)
+    with pytest.raises(Exception):
+        bim.get_image_dimensions(str(tmp_path / "movie.czi"))                          # needs aicsimageio: fails loudly
+
+
+def test_concatenate_time_points_golden(tmp_path):
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    g = np.load(os.path.join(ROOT, "tests", "golden", "drivers.npz"))
+    f1, f2 = str(tmp_path / "c1.npy"), str(tmp_path / "c2.npy")
+    np.save(f1, g["cat_1"]); np.save(f2, g["cat_2"])
+    out = bim.concatenate_time_points([f1, f2])
+    assert out.dtype == np.uint16
+    np.testing.assert_array_equal(out, g["cat_out"])
+
+
+def test_seg_archive_written_by_the_reference(tmp_path):
+    """tests/golden/ref_tissue.seg was written by the reference's Tissue.save (tools/make_goldens.py gold_seg, which also
+    checked there that the reference's Tissue.load reads an archive written by this package): this package's Tissue loads
+    it, holds what seg.npz says it holds, and writes an archive with the same members that loads back identically."""
+    import zipfile
+    from tissue_image_processing_amd import tissue_info as ti
+    g = np.load(os.path.join(ROOT, "tests", "golden", "seg.npz"))
+    assert bool(g["mine_reads_reference"]) and bool(g["reference_reads_mine"])
+    t = ti.Tissue(3, "movie", [])
+    steps = list(t.load(os.path.join(ROOT, "tests", "golden", "ref_tissue.seg")))
+    assert steps and steps[0] == 0 and all(a <= b for a, b in zip(steps, steps[1:]))      # a progress generator, like upstream's
+    np.testing.assert_array_equal(t.drifts, g["drifts"])
+    np.testing.assert_array_equal(t.valid_frames, g["valid_frames"])
+    assert t.type_names == [str(v) for v in g["type_names"]] and list(t.channel_names) == [str(v) for v in g["channel_names"]]
+    assert t.get_labels(2) is None and t.get_cells_info(2) is None
+    for f in (1, 3):
+        np.testing.assert_array_equal(t.get_labels(f), g["labels_%d" % f])
+        np.testing.assert_array_equal(t.get_cell_types(f), g["types_%d" % f])
+        info = t.get_cells_info(f)
+        for col in ("area", "perimeter", "label", "cx", "cy", "n_neighbors", "valid", "type", "bounding_box_min_row",
+                    "bounding_box_max_col", "empty_cell"):
+            np.testing.assert_array_equal(np.asarray(info[col].to_numpy(), dtype=np.float64), g["info_%d_%s" % (f, col)])
+        nb = g["info_%d_neighbors" % f]
+        for i, s in enumerate(info.neighbors):
+            assert sorted(int(v) for v in s) == [int(v) for v in nb[i] if v > 0]
+    out = str(tmp_path / "again")
+    list(t.save(out))
+    assert sorted(zipfile.ZipFile(out + ".seg").namelist()) == [str(v) for v in g["members"]]
+    u = ti.Tissue(3, "movie2", [])
+    list(u.load(out + ".seg"))
+    for f in (1, 3):
+        np.testing.assert_array_equal(u.get_labels(f), t.get_labels(f))
+        assert u.get_cells_info(f).equals(t.get_cells_info(f))
+    np.testing.assert_array_equal(u.drifts, t.drifts)

@@ -4,7 +4,9 @@ Same function names, argument meaning, return dtypes and error behaviour as the 
     put_channel_axis_first(image, axes)                              bim.py:199-231   (pure view logic, host)
     blur_image(image, std)                                           bim.py:373-390   -> tip_gaussian3d_w
     watershed_segmentation(image, imgthresh, stdeviation, blocksize) bim.py:446-476   -> tip_watershed_segmentation
-File I/O (read_tiff, save_tiff, ...) is out of scope.
+    read_image_in_chunks / get_image_dimensions / concatenate_time_points / read_tiff / save_tiff
+                                                                     bim.py:28-188, 478-495 (host I/O around the GPU path;
+                                                                     image sources: arrays, .npy, TIFF stacks, aicsimageio objects)
 """
 import ctypes
 
@@ -253,3 +255,252 @@ def save_tiff(path, image, metadata=None, axes="", data_type=""):
             fh.write(planes[k].tobytes())
             offset = nxt
     return
+
+
+# ---- image sources and the chunk iterator (bim.py:28-159, 478-495) -------------------------------------------------------
+# The reference opens everything through aicsimageio (absent in this image).  Here an image source is anything that can
+# say its (T, C, Z, Y, X) extents and hand out 5-D sub-blocks:
+#   * a numpy array / memmap of rank 5 (TCZYX), or a list / tuple of them (one per scene = microscope position);
+#   * a path to a .npy file (memory-mapped) or to an uncompressed TIFF stack (the reader below; axes from save_tiff's
+#     or ImageJ's ImageDescription);
+#   * an object with aicsimageio's interface (set_scene, dims, get_image_dask_data) -- a real AICSImage where that
+#     package is installed; any other path is handed to aicsimageio and fails loudly without it.
+class ImageDims(tuple):
+    """(T, C, Z, Y, X) with aicsimageio-style attribute access (dims.T, dims.C, ...)."""
+    __slots__ = ()
+    _names = "TCZYX"
+
+    def __new__(cls, t, c, z, y, x):
+        return tuple.__new__(cls, (int(t), int(c), int(z), int(y), int(x)))
+
+    def __getattr__(self, name):
+        i = ImageDims._names.find(name)
+        if i < 0 or len(name) != 1:
+            raise AttributeError(name)
+        return self[i]
+
+
+class _ArraySource(object):
+    def __init__(self, scenes):
+        self.scenes = scenes
+        self.scene = 0
+
+    def set_scene(self, series):
+        if not (0 <= series < len(self.scenes)):
+            raise IndexError("scene %d of %d" % (series, len(self.scenes)))
+        self.scene = series
+
+    @property
+    def dims(self):
+        return ImageDims(*self.scenes[self.scene].shape)
+
+    def block(self, t, c, z, y, x):
+        return np.asarray(self.scenes[self.scene][t, c, z, y, x])
+
+
+class _AicsSource(object):
+    def __init__(self, img):
+        self.img = img
+        self.data = None
+
+    def set_scene(self, series):
+        self.img.set_scene(series)
+        self.data = None
+
+    @property
+    def dims(self):
+        d = self.img.dims
+        return ImageDims(d.T, d.C, d.Z, d.Y, d.X)
+
+    def block(self, t, c, z, y, x):
+        if self.data is None:
+            self.data = self.img.get_image_dask_data()
+        chunk = self.data[t, c, z, y, x]
+        return np.asarray(chunk.compute() if hasattr(chunk, "compute") else chunk)
+
+
+def _as_tczyx(arr, axes):
+    """View of `arr` (axes named by `axes`, a subset of TCZYX in any order) as a 5-D TCZYX array."""
+    arr = np.asarray(arr) if not isinstance(arr, np.memmap) else arr
+    axes = axes.upper()
+    if len(axes) != arr.ndim or any(a not in "TCZYX" for a in axes) or len(set(axes)) != len(axes):
+        raise ValueError("axes %r do not describe an array of rank %d" % (axes, arr.ndim))
+    order = [axes.index(a) for a in "TCZYX" if a in axes]
+    view = np.transpose(arr, order)
+    shape, k = [], 0
+    for a in "TCZYX":
+        if a in axes:
+            shape.append(view.shape[k])
+            k += 1
+        else:
+            shape.append(1)
+    return view.reshape(shape)
+
+
+def open_image(source, series=0):
+    """The image-source object for `source` (see above), positioned on scene `series`."""
+    import os
+    if hasattr(source, "block") and hasattr(source, "dims"):
+        src = source
+    elif hasattr(source, "get_image_dask_data"):
+        src = _AicsSource(source)
+    elif isinstance(source, (list, tuple)):
+        src = _ArraySource([_as_tczyx(a, "TCZYX"[5 - np.ndim(a):]) for a in source])
+    elif isinstance(source, np.ndarray):
+        src = _ArraySource([_as_tczyx(source, "TCZYX"[5 - source.ndim:])])
+    elif isinstance(source, (str, bytes, os.PathLike)):
+        path = os.fspath(source)
+        ext = os.path.splitext(path)[1].lower()
+        if ext == ".npy":
+            arr = np.load(path, mmap_mode="r")
+            src = _ArraySource([_as_tczyx(arr, "TCZYX"[5 - arr.ndim:])])
+        elif ext in (".tif", ".tiff"):
+            image, axes, _, _ = read_tiff(path)
+            src = _ArraySource([_as_tczyx(image, axes if axes else "TCZYX"[5 - image.ndim:])])
+        else:
+            try:
+                from aicsimageio import AICSImage
+                from aicsimageio.readers import bioformats_reader
+            except ImportError as e:
+                raise _lib.TissueHipError("reading %r needs aicsimageio (with bioformats), which is not installed: %s; "
+                                          "convert the movie to .npy / TIFF or pass an array" % (path, e))
+            src = _AicsSource(AICSImage(path, reader=bioformats_reader.BioformatsReader))
+    else:
+        raise TypeError("cannot open %r as an image" % (type(source),))
+    src.set_scene(series)
+    return src
+
+
+def get_image_dimensions(path, series=0):
+    """bim.py:80-83."""
+    return open_image(path, series).dims
+
+
+def read_image_in_chunks(path, series=0, dx=0, dy=0, dz=0, dc=0, dt=0, apply_function=None, output=None,
+                         **apply_function_params):
+    """bim.py:89-159: generator over the (dt, dc, dz, dy, dx) blocks of scene `series`, x fastest, then y, z, c, t.
+    Without `apply_function` the blocks themselves are yielded; with it, its result per block -- and, when `output`
+    is given, each result is also reshaped into the block's place in `output` (a 5-D TCZYX array, or a list of them when
+    the function returns a tuple; an output axis shorter than the image is clipped, which is how the projection's
+    z axis of length 1 takes a whole z range).  `path` is any image source of open_image()."""
+    src = open_image(path, series)
+    ext = src.dims                                    # (T, C, Z, Y, X)
+    step = [d if d else e for d, e in zip((dt, dc, dz, dy, dx), ext)]
+    starts = [range(0, e, s) for e, s in zip(ext, step)]
+    for t in starts[0]:
+        for c in starts[1]:
+            for z in starts[2]:
+                for y in starts[3]:
+                    for x in starts[4]:
+                        lo = (t, c, z, y, x)
+                        hi = tuple(min(a + s, e) for a, s, e in zip(lo, step, ext))
+                        chunk = src.block(*[slice(a, b) for a, b in zip(lo, hi)])
+                        if apply_function is None:
+                            yield chunk
+                            continue
+                        result = apply_function(chunk, **apply_function_params)
+                        if output is None:
+                            continue                  # (bim.py:121-146 yields nothing in this case)
+                        single = not isinstance(result, tuple)
+                        results = [result] if single else list(result)
+                        outputs = [output] if single else output
+                        for res, out in zip(results, outputs):
+                            a = [min(p, n) for p, n in zip(lo, out.shape)]
+                            b = [min(q, n) for q, n in zip(hi, out.shape)]
+                            box = tuple(slice(p, q) for p, q in zip(a, b))
+                            out[box] = np.reshape(res, [q - p for p, q in zip(a, b)])
+                        yield result
+
+
+def _tiff_axes_from_description(desc, npages, rows, cols):
+    """(axes, shape) from the first page's ImageDescription: save_tiff's "axes=... shape=...", ImageJ's hyperstack
+    keys, else a plain page stack."""
+    import re
+    m = re.search(r"axes=([A-Za-z]*) shape=([0-9x]+)", desc)
+    if m and m.group(2):
+        shape = tuple(int(v) for v in m.group(2).split("x"))
+        if int(np.prod(shape)) == npages * rows * cols:
+            return m.group(1).upper(), shape
+    if desc.startswith("ImageJ="):
+        keys = dict(line.split("=", 1) for line in desc.splitlines() if "=" in line)
+        t, z, c = int(keys.get("frames", 1)), int(keys.get("slices", 1)), int(keys.get("channels", 1))
+        if t * z * c == npages:
+            axes, shape = "", ()
+            for name, n in (("T", t), ("Z", z), ("C", c)):
+                if n > 1:
+                    axes += name
+                    shape += (n,)
+            return axes + "YX", shape + (rows, cols)
+    if npages > 1:
+        return "QYX", (npages, rows, cols)           # (tifffile's name for an unknown page axis)
+    return "YX", (rows, cols)
+
+
+def read_tiff(path):
+    """bim.py:28-51: (image, axes, shape, metadata) of a TIFF file.  Self-contained reader for what this package and
+    ImageJ write -- classic (non-Big) TIFF, either byte order, uncompressed strips, one sample per pixel, 8 / 16 / 32-bit
+    unsigned, signed or float pages of one size; anything else raises."""
+    import struct
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if len(buf) < 8 or buf[:2] not in (b"II", b"MM"):
+        raise ValueError("%s is not a TIFF file" % path)
+    bo = "<" if buf[:2] == b"II" else ">"
+    magic, ifd = struct.unpack(bo + "HI", buf[2:8])
+    if magic != 42:
+        raise ValueError("%s: only classic TIFF is read here (magic %d)" % (path, magic))
+    sizes = {1: 1, 2: 1, 3: 2, 4: 4, 6: 1, 8: 2, 9: 4, 16: 8}
+    codes = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 16: "Q"}
+    pages, desc = [], ""
+    while ifd:
+        n, = struct.unpack(bo + "H", buf[ifd:ifd + 2])
+        tags = {}
+        for k in range(n):
+            tag, typ, cnt, raw = struct.unpack(bo + "HHI4s", buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k])
+            if typ not in sizes:
+                continue
+            nbytes = sizes[typ] * cnt
+            data = raw[:nbytes] if nbytes <= 4 else buf[struct.unpack(bo + "I", raw)[0]:][:nbytes]
+            tags[tag] = data if typ == 2 else struct.unpack(bo + "%d%s" % (cnt, codes[typ]), data)
+        ifd, = struct.unpack(bo + "I", buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
+        if tags.get(259, (1,))[0] != 1 or tags.get(277, (1,))[0] != 1:
+            raise ValueError("%s: compressed or multi-sample pages are not read here" % path)
+        cols, rows, bits = tags[256][0], tags[257][0], tags.get(258, (1,))[0]
+        kind = {1: "u", 2: "i", 3: "f"}[tags.get(339, (1,))[0]]
+        dtype = np.dtype("%s%s%d" % (bo, kind, bits // 8))
+        offs, counts = tags[273], tags.get(279, (rows * cols * dtype.itemsize,))
+        raw = b"".join(buf[o:o + c] for o, c in zip(offs, counts))
+        pages.append(np.frombuffer(raw, dtype=dtype, count=rows * cols).reshape(rows, cols))
+        if not desc and 270 in tags:
+            desc = tags[270].split(b"\0")[0].decode("latin-1")
+    if not pages:
+        raise ValueError("%s holds no image" % path)
+    if any(p.shape != pages[0].shape or p.dtype != pages[0].dtype for p in pages):
+        raise ValueError("%s: pages of different size or type" % path)
+    rows, cols = pages[0].shape
+    axes, shape = _tiff_axes_from_description(desc, len(pages), rows, cols)
+    image = np.stack(pages).astype(pages[0].dtype.newbyteorder("=")).reshape(shape)
+    metadata = dict(line.split("=", 1) for line in desc.splitlines() if "=" in line) if desc.startswith("ImageJ=") else None
+    return image, axes, image.shape, metadata
+
+
+def concatenate_time_points(files):
+    """bim.py:478-495: the per-movie projection files (.npy, time first) as one uint16 movie.  A later movie with fewer
+    channels (axes 1 .. ndim-3) than the first is zero-padded at the FRONT of that axis.  (The reference also means to
+    resize frames of a different (Y, X) size but passes skimage a nested tuple and raises there; so does this.)"""
+    movies = []
+    for f in files:
+        img = np.load(f).astype("uint16")
+        if movies:
+            first = movies[0]
+            for dim in range(1, img.ndim - 2):
+                missing = first.shape[dim] - img.shape[dim]
+                if missing > 0:
+                    pad = [(0, 0)] * img.ndim
+                    pad[dim] = (missing, 0)
+                    img = np.pad(img, pad_width=pad, constant_values=0)
+            if img.shape[-2:] != first.shape[-2:]:
+                raise ValueError("concatenate_time_points: frame size %s differs from the first movie's %s"
+                                 % (img.shape[-2:], first.shape[-2:]))
+        movies.append(img)
+    return np.concatenate(movies, axis=0)

@@ -425,9 +425,16 @@ class TissueHipMixin(object):
         return out
 
 
+EVENTS_INFO_SPEC = {"type": "TBA", "start_frame": 0, "end_frame": 0, "start_pos_x": 0, "start_pos_y": 0, "end_pos_x": 0,
+                    "end_pos_y": 0, "daughter_pos_x": 0, "daughter_pos_y": 0, "cell_id": 0, "daughter_id": 0,
+                    "significant_frame": 0, "source": "manual"}      # ti.py:53-65
+
+
 class Tissue(TissueHipMixin):
-    """Minimal in-memory host of the hot methods (per-frame labels / cell tables / type maps kept in lists).
-    The reference's own Tissue (state, caching, .seg persistence, events, statistics) is out of scope."""
+    """In-memory host of the hot methods (per-frame labels / cell tables / type maps kept in lists) that reads and writes
+    the reference's `.seg` archives (ti.py:3474-3524, 3616-3757), so that the unmodified GUI opens what the GPU pipeline
+    produced and vice versa.  The reference's interactive state (undo, line drawing, events editing, statistics) is out
+    of scope."""
 
     def __init__(self, number_of_frames, data_path=None, channel_names=(), max_cell_area=10, min_cell_area=0.1,
                  load_to_memory=True):
@@ -446,6 +453,97 @@ class Tissue(TissueHipMixin):
         self.last_action = []
         self._neighbors_labels = (0, 0)
         self.last_added_line = []
+        self.events = make_df(0, EVENTS_INFO_SPEC)
+        self.shape_fitting_results = [dict() for _ in range(number_of_frames)]
+        self.fake_channels = []
+
+    # -- .seg archives: a flat zip (deflate) of per-frame files and movie-wide tables; member names as upstream ---------
+    def _archive_members(self):
+        """(member name, writer(file object)) for everything that is set."""
+        import json
+        import pickle
+        members = []
+        for k in range(self.number_of_frames):
+            frame = k + 1
+            if self._labels[k] is not None:
+                members.append(("frame_%d_labels.npy" % frame, lambda fh, a=self._labels[k]: np.save(fh, a)))
+            if self._cell_types[k] is not None:
+                members.append(("frame_%d_types.npy" % frame, lambda fh, a=self._cell_types[k]: np.save(fh, a)))
+            if self._cells_info[k] is not None:
+                members.append(("frame_%d_data.pkl" % frame, lambda fh, df=self._cells_info[k]: df.to_pickle(fh, compression=None)))
+        members.append(("events_data.pkl", lambda fh: self.events.to_pickle(fh, compression=None)))
+        if self.drifts is not None:
+            members.append(("drifts.npy", lambda fh: np.save(fh, self.drifts)))
+        if self.valid_frames is not None:
+            members.append(("valid_frames.npy", lambda fh: np.save(fh, self.valid_frames)))
+        members.append(("shape_fitting_data.json", lambda fh: fh.write(json.dumps(self.shape_fitting_results).encode())))
+        for name, value in (("cell_type_names.pkl", self.type_names), ("channel_names.pkl", self.channel_names),
+                            ("fake_channels.pkl", self.fake_channels)):
+            if value is not None:
+                members.append((name, lambda fh, v=value: pickle.dump(v, fh)))
+        return members
+
+    def save(self, path):
+        """ti.py:3716-3731: write `<path>.seg`; a generator of percent done, like upstream's (the GUI drives a progress
+        bar with it)."""
+        import io
+        import zipfile
+        members = self._archive_members()
+        with zipfile.ZipFile(path.replace(".seg", "") + ".seg", "w", zipfile.ZIP_DEFLATED) as z:
+            for i, (name, write) in enumerate(members):
+                yield 100.0 * i / len(members)
+                buf = io.BytesIO()
+                write(buf)
+                z.writestr(name, buf.getvalue())
+        return 0
+
+    def load(self, path, type_name=""):
+        """ti.py:3733-3757: read a `.seg` archive (written here or by the reference); generator of percent done.
+        Old single-type archives are upgraded as upstream does (ti.py:4211-4228)."""
+        import io
+        import json
+        import pickle
+        import re
+        import zipfile
+        with zipfile.ZipFile(path, "r") as z:
+            names = z.namelist()
+            for i, name in enumerate(names):
+                yield 100.0 * i / len(names)
+                raw = io.BytesIO(z.read(name))
+                m = re.fullmatch(r"frame_(\d+)_(labels\.npy|types\.npy|data\.pkl)", name)
+                if m:
+                    k = int(m.group(1)) - 1
+                    if not (0 <= k < self.number_of_frames):
+                        continue
+                    if m.group(2) == "labels.npy":
+                        self._labels[k] = np.load(raw)
+                    elif m.group(2) == "types.npy":
+                        types = np.load(raw)
+                        if types.max() <= 2 and types.min() >= 0:          # old version: 0 meant invalid
+                            types[types == 0] = INVALID_TYPE_INDEX
+                        self._cell_types[k] = types
+                    else:
+                        info = pd.read_pickle(raw, compression=None)
+                        if len(info) and isinstance(info.at[info.index[0], "type"], str):
+                            info.replace({"HC": 1, "SC": 0, "invalid": 0}, inplace=True)
+                            if type_name and not self.type_names:
+                                self.type_names = [type_name]
+                        self._cells_info[k] = info
+                elif name == "events_data.pkl":
+                    self.events = pd.concat([self.events, pd.read_pickle(raw, compression=None)])
+                elif name == "drifts.npy":
+                    self.drifts = np.load(raw)
+                elif name == "valid_frames.npy":
+                    self.valid_frames = np.load(raw)
+                elif name == "shape_fitting_data.json":
+                    self.shape_fitting_results = json.loads(raw.getvalue().decode())
+                elif name == "cell_type_names.pkl":
+                    self.type_names = pickle.load(raw)
+                elif name == "channel_names.pkl":
+                    self.channel_names = pickle.load(raw)
+                elif name == "fake_channels.pkl":
+                    self.fake_channels = pickle.load(raw)
+        return 0
 
     def set_labels(self, frame_number, labels, reset_data=False):
         if reset_data:

@@ -550,6 +550,174 @@ def gold_percentile():
          p95_f64=np.array(np.percentile(nz.astype(np.float64), 95)))
 
 
+# ---- drivers (sp.py:168-316, bim.py:89-159, 478-495): the reference's own functions over an in-memory stand-in for the
+# absent aicsimageio reader / OME-TIFF writer (arrays registered under file names; the writer records what it is given)
+class _Lazy(object):
+    def __init__(self, a):
+        self.a = a
+
+    def __getitem__(self, k):
+        return _Lazy(self.a[k])
+
+    def compute(self):
+        return np.asarray(self.a)
+
+
+class _NS(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _FakeImage(object):
+    registry = {}
+
+    def __init__(self, path, reader=None):
+        self.scenes = _FakeImage.registry[path]
+        self.scene = 0
+
+    def set_scene(self, i):
+        self.scene = i
+
+    @property
+    def dims(self):
+        t, c, z, y, x = self.scenes[self.scene].shape
+        return _NS(T=t, C=c, Z=z, Y=y, X=x)
+
+    def get_image_dask_data(self):
+        return _Lazy(self.scenes[self.scene])
+
+    @property
+    def metadata(self):
+        images = []
+        for i, a in enumerate(self.scenes):
+            images.append(_NS(name="s%d" % i, stage_label=_NS(x=100.0 * i + 1.5, y=-20.0 - i, z=3.25 + i, x_unit="um", y_unit="um", z_unit="um"),
+                              pixels=_NS(size_t=a.shape[0], size_c=a.shape[1], size_z=a.shape[2], dimension_order="XYZCT", type="uint16",
+                                         physical_size_x=0.1, physical_size_y=0.1, physical_size_z=0.5, planes=list(range(a.shape[1] * 3)))))
+        return _NS(images=images)
+
+
+class _FakeWriter(object):
+    saved = {}
+
+    @staticmethod
+    def save(image, path, dim_order="", ome_xml=None):
+        _FakeWriter.saved[os.path.basename(path)] = (np.array(image), dim_order)
+
+
+def gold_drivers():
+    import pickle
+    bim.AICSImage = _FakeImage
+    bim.bioformats_reader = _NS(BioformatsReader=None)
+    bim.ome_tiff_writer = _NS(OmeTiffWriter=_FakeWriter)
+    out = {}
+    mk = lambda T, seed, Z=6, Y=40, X=56: np.stack([synthetic.make_stack(Z, Y, X, seed=seed + t) for t in range(T)])
+    # (1) chunk iterator with the projection as apply_function: blocks of 32 x 24 pixels, one time point at a time
+    a = mk(2, 300)
+    _FakeImage.registry["chunks.czi"] = [a]
+    proj = np.zeros((2, 2, 1, 40, 56)); zmap = np.zeros((2, 1, 1, 40, 56))
+    n = 0
+    for _ in bim.read_image_in_chunks("chunks.czi", dx=32, dy=24, dt=1, apply_function=sp.time_point_surface_projection,
+                                      output=[proj, zmap], axes="TCZYX", reference_channel=0, z_map=True, airyscan=False):
+        n += 1
+    raw = [c.shape for c in bim.read_image_in_chunks("chunks.czi", dx=30, dz=4, dc=1)]
+    out.update(ch_stack=a, ch_proj=proj, ch_zmap=zmap, ch_n=np.array(n), ch_raw_shapes=np.array(raw))
+    with tempfile.TemporaryDirectory() as tmp:
+        # (2) large_image_projection: scalar position (T = 1) and a list of positions (T = 2)
+        big1, big2 = mk(1, 310, Y=48, X=64), mk(2, 320, Y=48, X=64)
+        open(os.path.join(tmp, "big.czi"), "w").close()
+        _FakeImage.registry[os.path.join(tmp, "big.czi")] = [big1, big1[:, ::-1].copy()]
+        sp.large_image_projection(tmp, tmp, "big.czi", position=1, reference_channel=0, chunk_size=32, method="max_averages")
+        out.update(li_stack=big1, li_tif=_FakeWriter.saved["big_projection.tif"][0],
+                   li_axes=np.array(_FakeWriter.saved["big_projection.tif"][1]), li_zmap=np.load(os.path.join(tmp, "big_zmap.npy")))
+        open(os.path.join(tmp, "bigt.czi"), "w").close()
+        _FakeImage.registry[os.path.join(tmp, "bigt.czi")] = [big2, big2[:, ::-1].copy()]
+        sp.large_image_projection(tmp, tmp, "bigt.czi", position=[1, 2], reference_channel=1, chunk_size=40, method="max_averages",
+                                  channels_shift=-1)
+        out.update(lt_stack=big2, lt_tif1=_FakeWriter.saved["bigt_position1_projection.tif"][0],
+                   lt_tif2=_FakeWriter.saved["bigt_position2_projection.tif"][0],
+                   lt_axes=np.array(_FakeWriter.saved["bigt_position2_projection.tif"][1]),
+                   lt_zmap2=np.load(os.path.join(tmp, "bigt_position2_zmap.npy")))
+        # (3) movie over two files: position 0 ends with movie 1, position 1 goes on (as scene 0 of movie 2)
+        m1a, m1b, m2b = mk(2, 330), mk(2, 340), mk(1, 350)
+        _FakeImage.registry["m1.czi"] = [m1a, m1b]
+        _FakeImage.registry["m2.czi"] = [m2b]
+        odir = os.path.join(tmp, "movie"); os.mkdir(odir)
+        sp.movie_surface_projection(["m1.czi", "m2.czi"], 0, (1, 2), 2, odir, "max_averages", 1, False, 0, 0, 0, False, output_name="x_")
+        out.update(mv_m1a=m1a, mv_m1b=m1b, mv_m2b=m2b, mv_tif1=_FakeWriter.saved["x_position1.tif"][0], mv_tif2=_FakeWriter.saved["x_position2.tif"][0],
+                   mv_zmap1=np.load(os.path.join(odir, "x_zmap_position1.npy")), mv_zmap2=np.load(os.path.join(odir, "x_zmap_position2.npy")),
+                   mv_left=np.array(sorted(os.listdir(odir))))
+        for k in (1, 2):
+            st = pickle.load(open(os.path.join(odir, "x_stage_locations_position%d.pkl" % k), "rb"))
+            out["mv_stage%d_xyz" % k] = np.array([st["x"], st["y"], st["z"]])
+            out["mv_stage%d_misc" % k] = np.array([st["x_unit"], st["y_unit"], st["z_unit"], repr(st["physical_size_x"]),
+                                                   repr(st["physical_size_y"]), repr(st["physical_size_z"])])
+        # (4) concatenate_time_points: the second movie has one channel less
+        rng = np.random.default_rng(360)
+        c1, c2 = rng.random((2, 2, 8, 9)) * 70000, rng.random((1, 1, 8, 9)) * 900
+        np.save(os.path.join(tmp, "c1.npy"), c1); np.save(os.path.join(tmp, "c2.npy"), c2)
+        out.update(cat_1=c1, cat_2=c2, cat_out=bim.concatenate_time_points([os.path.join(tmp, "c1.npy"), os.path.join(tmp, "c2.npy")]))
+    save("drivers", **out)
+
+
+def gold_seg():
+    """The `.seg` archive (ti.py:3716-3757): one written by the reference's Tissue.save (committed as a data fixture next
+    to the arrays it holds), and a cross-check in both directions with this repository's reader / writer."""
+    import shutil
+    from tissue_image_processing_amd import tissue_info as mine
+    g = np.load(os.path.join(OUT, "cellinfo.npz"))
+    lab1 = g["a_labels"]
+    lab2 = np.roll(lab1, 3, axis=1)
+    tmp = tempfile.mkdtemp(prefix="tipgold_")
+    t = ti.Tissue(3, os.path.join(tmp, "movie_s"), ["zo", "atoh"])
+    for frame, lab in ((1, lab1), (3, lab2)):
+        t.set_labels(frame, lab.copy(), reset_data=True)
+        t.calculate_frame_cellinfo(frame)
+        types = np.full(lab.shape, ti.INVALID_TYPE_INDEX, dtype=np.uint8)
+        types[lab % 3 == 1] = 1
+        types[lab % 3 == 2] = 2
+        t.set_cell_types(frame, types)
+    t.drifts[1] = (1.25, -3.5)
+    t.drifts[2] = (-0.5, 2.0)
+    t.set_validity_of_frame(2, False)
+    t.type_names = ["HC"]
+    path = os.path.join(tmp, "ref_tissue")
+    for _ in t.save(path):
+        pass
+    shutil.copy(path + ".seg", os.path.join(OUT, "ref_tissue.seg"))
+    out = {"drifts": t.drifts.copy(), "valid_frames": t.valid_frames.copy(), "type_names": np.array(t.type_names),
+           "channel_names": np.array(t.channel_names)}
+    for frame in (1, 3):
+        out["labels_%d" % frame] = t.get_labels(frame).copy()
+        out["types_%d" % frame] = t.get_cell_types(frame).copy()
+        for k, v in _cells_table(t, frame).items():
+            out["info_%d_%s" % (frame, k)] = v
+    import zipfile
+    out["members"] = np.array(sorted(zipfile.ZipFile(path + ".seg").namelist()))
+    # cross-check 1: this repository's Tissue reads the reference's archive
+    m = mine.Tissue(3, "x", [])
+    for _ in m.load(path + ".seg"):
+        pass
+    ok = all(np.array_equal(m.get_labels(f), t.get_labels(f)) and np.array_equal(m.get_cell_types(f), t.get_cell_types(f)) and
+             m.get_cells_info(f).equals(t.get_cells_info(f)) for f in (1, 3))
+    ok = ok and np.array_equal(m.drifts, t.drifts) and np.array_equal(m.valid_frames, t.valid_frames) and m.type_names == t.type_names
+    # cross-check 2: the reference's Tissue reads an archive written by this repository's Tissue
+    mpath = os.path.join(tmp, "mine")
+    for _ in m.save(mpath):
+        pass
+    r = ti.Tissue(3, os.path.join(tmp, "movie_r"), [])
+    for _ in r.load(mpath + ".seg"):
+        pass
+    ok2 = all(np.array_equal(r.get_labels(f), t.get_labels(f)) and np.array_equal(r.get_cell_types(f), t.get_cell_types(f)) and
+              r.get_cells_info(f).equals(t.get_cells_info(f)) for f in (1, 3))
+    ok2 = ok2 and np.array_equal(r.drifts, t.drifts) and np.array_equal(r.valid_frames, t.valid_frames) and \
+        r.type_names == t.type_names and list(r.channel_names) == list(t.channel_names)
+    ok2 = ok2 and sorted(zipfile.ZipFile(mpath + ".seg").namelist()) == sorted(zipfile.ZipFile(path + ".seg").namelist())
+    out["mine_reads_reference"] = np.array(bool(ok))
+    out["reference_reads_mine"] = np.array(bool(ok2))
+    assert ok and ok2, (ok, ok2)
+    save("seg", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gold_weights()
@@ -567,4 +735,6 @@ if __name__ == "__main__":
     gold_unet_predict()
     gold_tracking()
     gold_drift()
+    gold_drivers()
+    gold_seg()
     print("done")
