@@ -76,6 +76,13 @@ TIP_API int tip_gaussian3d_f32(const float *in, float *out, int z, int y, int x,
                                double sz, double sy, double sx, double truncate);
 TIP_API int tip_gaussian2d_f64(const double *in, double *out, int y, int x, double sy, double sx, double truncate);
 
+/* OR-ed into `method` of tip_project_u16_binned[_dev]: build_manifold=True (sp.py:56-57, 87-165), the z-map grown as a
+ * spiral around the score's maximum instead of the per-pixel argmax.  bin_size must be 1; min_z is not added to the
+ * z-map (as upstream). */
+#define TIP_PROJECT_MANIFOLD 16
+/* build_continues_manifold(score) itself (sp.py:87-165): score float32 (z, y, x) -> chosen int64 (y, x); host arrays. */
+TIP_API int tip_build_manifold_f32(const float *score, int z, int y, int x, int64_t *chosen);
+
 /* ---- surface projection: sp.py:17-85 (build_manifold=False) ---------------------------------- */
 /* czyx: uint16 (C,Z,Y,X).  [zlo,zhi) is the z slice sp.py:30-31 takes when max_z>0 (else 0,Z).   */
 /* taps: scipy taps for sigma 0.5 (5), 1 (9), 2 (17), 30 (241); pass NULL to have them built with */

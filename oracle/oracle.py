@@ -30,6 +30,7 @@ def lib():
         _LIB = ctypes.CDLL(path)
         _LIB.orc_gaussian_weights.restype = ctypes.c_long
         _LIB.orc_label4_i32.restype = ctypes.c_long
+        _LIB.orc_build_manifold_f32.restype = ctypes.c_long
     return _LIB
 
 
@@ -309,13 +310,23 @@ def resize_linear(a, out_yx):
     return t.astype(np.float32)
 
 
+def build_continues_manifold(score):
+    """sp.py:87-165: the spiral z-map (C restatement orc_build_manifold_f32; int64 like upstream's astype(int))."""
+    s = np.ascontiguousarray(score, dtype=np.float32)
+    out = np.empty(s.shape[1:], np.int64)
+    rc = lib().orc_build_manifold_f32(_p(s), ctypes.c_long(s.shape[0]), ctypes.c_long(s.shape[1]), ctypes.c_long(s.shape[2]), _p(out))
+    if rc:
+        raise TypeError("unsupported operand type(s) for -: 'NoneType' and 'int'")   # what upstream raises there
+    return out
+
+
 def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, max_z=0,
                                   method="max_averages", bin_size=1, airyscan=True, z_map=False,
                                   atoh_shift=0, build_manifold=False, clip_from=None):
-    """sp.py:17-85 (build_manifold False).  clip_from (not in the reference): the array whose non-zero 95th percentile
+    """sp.py:17-85 (build_manifold with bin_size 1 only).  clip_from (not in the reference): the array whose non-zero 95th percentile
     clips the reference channel instead of the channel's own -- a spatial tile passes the whole frame's channel."""
-    if build_manifold:
-        raise NotImplementedError("oracle: build_manifold=False")
+    if build_manifold and bin_size > 1:
+        raise NotImplementedError("oracle: build_manifold with bin_size 1")
     if axes.find("T") >= 0:
         time_point = time_point.reshape(time_point.shape[1:])
         image, _ = put_channel_axis_first(time_point, axes[1:])
@@ -353,7 +364,7 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
         score = resize_linear(score, (y_size, x_size))
     else:
         score = blur_image(ch, (0.5, 30, 30))
-    chosen_z = min_z + np.argmax(score, axis=0)
+    chosen_z = build_continues_manifold(score) if build_manifold else min_z + np.argmax(score, axis=0)   # (sp.py:56-61)
     chosen_z_atoh = np.copy(chosen_z) if atoh_shift == 0 else np.clip(chosen_z + atoh_shift, 0, score.shape[0])
     mask = np.zeros((z_size, y_size * x_size), np.float32)
     mask_atoh = np.zeros((z_size, y_size * x_size), np.float32)

@@ -560,3 +560,73 @@ ORC_API int orc_hist_u16(const uint16_t *in, long n, int sub, int64_t *hist /* 6
     }
     return 0;
 }
+
+/* ---- build_continues_manifold (sp.py:87-165), restated: a square spiral around the first global maximum of score;
+ * every visited pixel takes its plane from the planes of its visited neighbours (find_pixel_plane, sp.py:131-165).
+ * score: float32 (Z, R, C); out: int64 (R, C).  Returns 0, or -1 when a pixel has no visited neighbour (upstream raises). */
+static long man_plane(const float *score, const long long *out, long r, long c, long Z, long R, long C, int *bad)
+{
+    const long P = R * C;
+    long nb[4], n1 = -1, n2 = -1, j;
+    nb[0] = (long)out[(r > 0 ? r - 1 : R - 1) * C + c];              /* chosen_z[row - 1]: row 0 wraps to the last row */
+    nb[1] = r < R - 1 ? (long)out[(r + 1) * C + c] : -1;
+    nb[2] = c > 0 ? (long)out[r * C + c - 1] : -1;
+    nb[3] = c < C - 1 ? (long)out[r * C + c + 1] : -1;
+    for (j = 0; j < 4; ++j) {                                        /* the first two visited neighbours, in that order */
+        if (nb[j] < 0) continue;
+        if (n1 < 0) n1 = nb[j];
+        else if (n2 < 0) n2 = nb[j];
+    }
+    if (n1 < 0) { *bad = 1; return 0; }
+    {
+        long lo, hi, z, best;
+        if (n2 < 0 || n1 == n2) { lo = n1 - 1 < 0 ? 0 : n1 - 1; hi = n1 + 2 > Z ? Z : n1 + 2; }
+        else if (n1 - n2 == 1 || n2 - n1 == 1) { lo = n1 < n2 ? n1 : n2; hi = lo + 2 > Z ? Z : lo + 2; }
+        else return (n1 + n2) / 2;                                   /* float mean stored into an integer array */
+        best = lo;
+        for (z = lo + 1; z < hi; ++z)
+            if (score[z * P + r * C + c] > score[best * P + r * C + c]) best = z;
+        return best;
+    }
+}
+
+ORC_API long orc_build_manifold_f32(const float *score, long Z, long R, long C, long long *out)
+{
+    const long P = R * C;
+    long i, best = 0, sp, sr, sc, d, dmax, row, col;
+    int bad = 0;
+    for (i = 0; i < P; ++i) out[i] = -1;
+    for (i = 1; i < Z * P; ++i)
+        if (score[i] > score[best]) best = i;
+    sp = best / P; sr = (best % P) / C; sc = best % C;
+    out[sr * C + sc] = sp;
+    dmax = sc;
+    if (sr > dmax) dmax = sr;
+    if (C - 1 - sc > dmax) dmax = C - 1 - sc;
+    if (R - 1 - sr > dmax) dmax = R - 1 - sr;
+#define MAN_SET(rr, cc) out[(rr) * C + (cc)] = man_plane(score, out, (rr), (cc), Z, R, C, &bad)
+    for (d = 1; d <= dmax; ++d) {
+        col = sc + d;                                                /* right edge, lower half */
+        if (col < C)
+            for (row = sr; row <= sr + d; ++row)
+                if (row < R) MAN_SET(row, col);
+        row = sr + d;                                                /* bottom edge, leftwards */
+        if (row < R)
+            for (col = sc + d - 1; col >= sc - d; --col)
+                if (col >= 0 && col < C) MAN_SET(row, col);
+        col = sc - d;                                                /* left edge, upwards */
+        if (col >= 0)
+            for (row = sr + d - 1; row >= sr - d; --row)
+                if (row >= 0 && row < R) MAN_SET(row, col);
+        row = sr - d;                                                /* top edge, rightwards */
+        if (row >= 0)
+            for (col = sc - d + 1; col <= sc + d; ++col)
+                if (col >= 0 && col < C) MAN_SET(row, col);
+        col = sc + d;                                                /* right edge, upper half */
+        if (col < C)
+            for (row = sr - d + 1; row < sr; ++row)
+                if (row >= 0) MAN_SET(row, col);
+    }
+#undef MAN_SET
+    return bad ? -1 : 0;
+}

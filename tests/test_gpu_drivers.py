@@ -19,6 +19,12 @@ def g():
     return np.load(os.path.join(ROOT, "tests", "golden", "drivers.npz"))
 
 
+@pytest.fixture(autouse=True)
+def _golden_taps(monkeypatch, golden_taps):
+    from gpu_util import taps_patch
+    taps_patch(monkeypatch, golden_taps)          # the taps of the interpreter that produced the goldens
+
+
 class _NS(object):
     def __init__(self, **kw):
         self.__dict__.update(kw)

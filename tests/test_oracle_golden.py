@@ -263,3 +263,21 @@ def test_drift(golden):
         np.testing.assert_array_equal(orc.phase_cross_correlation(imgs[0], imgs[1], 1), g[tag + "_calc_whole"])
         np.testing.assert_array_equal(orc.phase_cross_correlation(g[tag + "_prev_f64"], g[tag + "_cur_f64"], 100),
                                       g[tag + "_calc_f64"])
+
+
+def test_manifold_golden(golden):
+    """build_continues_manifold (sp.py:87-165): the oracle's serial C restatement equals the reference on every golden
+    case (start in the middle / corner / on an edge, the row-0 wrap quirk on short frames) and through the whole
+    projection with build_manifold=True."""
+    g = golden("manifold")
+    for k in g.files:
+        if k.startswith("m_") and k.endswith("_score"):
+            n = k[2:-6]
+            np.testing.assert_array_equal(orc.build_continues_manifold(g[k]), g["m_%s_z" % n], err_msg=n)
+    p, z = orc.time_point_surface_projection(g["p_stack"][None], "TCZYX", 0, airyscan=False, z_map=True, build_manifold=True)
+    np.testing.assert_array_equal(z, g["p_zmap"])
+    np.testing.assert_array_equal(p, g["p_proj"])
+    p, z = orc.time_point_surface_projection(g["p_stack"], "CZYX", 1, min_z=1, max_z=9, airyscan=False, z_map=True,
+                                             build_manifold=True, atoh_shift=-1)
+    np.testing.assert_array_equal(z, g["p2_zmap"])
+    np.testing.assert_array_equal(p, g["p2_proj"])

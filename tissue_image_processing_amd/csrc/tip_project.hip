@@ -10,6 +10,7 @@
 #include "tip_slide.h"
 #include "tip_preblur.h"
 #include "tip_corr_mfma2.h"
+#include "tip_manifold.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -871,6 +872,28 @@ static int resolve_taps(const double *given, double sigma, int expect, Taps &t)
     return make_taps(t, given, expect);
 }
 
+// build_continues_manifold on a device score (Zs, Y, X) -> plane index per pixel (int32, device); err bit 2: a pixel without
+// a visited neighbour
+static int manifold_dev(const float *score, int Zs, int Y, int X, int *bestz, int *err)
+{
+    Ctx &c = ctx();
+    const long P = (long)Y * X, V = (long)Zs * P;
+    if (V >= 0xffffffffL || Zs > 144 || Zs < 1) return fail(TIP_ERR_UNSUPPORTED, "build_manifold: stack too large");
+    WsGuard ws;
+    unsigned long long *key = ws.get<unsigned long long>(1);
+    if (!key) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemsetAsync(key, 0, sizeof(unsigned long long), c.stream));
+    TIP_HIP(hipMemsetAsync(bestz, 0xff, P * sizeof(int), c.stream));
+    TIP_LAUNCH("argmax_first", k_argmax_first_f32, dim3((unsigned)std::min<long>(1024, cdiv(V, 256))), dim3(256), 0, score, V, key);
+    int chunk = 1024;
+    while (chunk > 64 && (size_t)4 * Zs * chunk > 150000) chunk >>= 1;
+    const size_t lds = (size_t)4 * Zs * chunk;
+    TIP_HIP(hipFuncSetAttribute((const void *)k_manifold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TIP_LAUNCH("manifold", k_manifold, dim3(1), dim3(MAN_T), lds, score, Zs, Y, X, (const unsigned long long *)key, (volatile int *)bestz,
+               chunk, err);
+    return TIP_OK;
+}
+
 int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int zhi, int min_z, int ref_ch, int method, int bin,
                 int airyscan, int atoh_shift, const double *t05, const double *t1, const double *t2,
                 const double *t30, double *proj, int64_t *zmap, const unsigned long long *hist_in = nullptr)
@@ -884,6 +907,10 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     if (Y < 1 || X < 1 || Y > 65535) return fail(TIP_ERR_ARG, "project: bad frame size %dx%d", Y, X);
     const int Zs = zhi - zlo;
     const long P = (long)Y * X, V = (long)Zs * P;
+    const bool manifold = (method & TIP_PROJECT_MANIFOLD) != 0;      // sp.py:56-57: the spiral z-map instead of the argmax
+    method &= ~TIP_PROJECT_MANIFOLD;
+    if (manifold && (bin != 1 || hist_in)) return fail(TIP_ERR_UNSUPPORTED, "project: build_manifold takes bin_size 1, whole frames");
+    if (manifold && (V >= 0xffffffffL || Zs > 144)) return fail(TIP_ERR_UNSUPPORTED, "project: build_manifold: stack too large");
     Taps k05, k1, k2, k30;
     int rc;
     if ((rc = resolve_taps(t05, 0.5, 5, k05)) || (rc = resolve_taps(t1, 1.0, 9, k1)) ||
@@ -977,8 +1004,17 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                    zsel_a, zmap, err);
     } else {
     // P4 + P5: (0.5, 30, 30) score and its argmax
-    const bool certified = fast && Zs <= 64 && !getenv("TIP_PROJECT_EXACT_SCORE");
-    if (certified) {
+    const bool certified = fast && Zs <= 64 && !manifold && !getenv("TIP_PROJECT_EXACT_SCORE");
+    if (manifold) {
+        // the spiral reads score VALUES (window argmaxes), so it gets the exact score; min_z is not added (sp.py:57)
+        if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
+        if ((rc = correlate1d_dev(A, B, 0, Zs, Y, X, 2, k30, 0))) return rc;
+        int *bestz = ws.get<int>(P);
+        if (!bestz) return TIP_ERR_NOMEM;
+        if ((rc = manifold_dev((const float *)B, Zs, Y, X, bestz, err))) return rc;
+        TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, 0, atoh_shift, zsel, zsel_a,
+                   zmap, err);
+    } else if (certified) {
         float *D = ws.get<float>(V);
         int *bestz = ws.get<int>(P), *unc = ws.get<int>(P), *uncn = ws.get<int>(1);
         if (!D || !bestz || !unc || !uncn) return TIP_ERR_NOMEM;
@@ -1037,10 +1073,11 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                        airyscan, cm, k2, proj);
         }
     }
-    if (min_z > 0 || atoh_shift > 0) {
+    if (min_z > 0 || atoh_shift > 0 || manifold) {
         int h = 0;
         TIP_HIP(hipMemcpyAsync(&h, err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
         TIP_HIP(hipStreamSynchronize(c.stream));
+        if (h & 2) return fail(TIP_ERR_HIP, "build_manifold: a pixel without a visited neighbour (upstream raises TypeError here)");
         if (h)
             return fail(TIP_ERR_INDEX, "chosen z index out of bounds for the %d-plane mask (min_z=%d, atoh_shift=%d): "
                                        "the reference raises IndexError here (sp.py:62,68-69)", Zs, min_z, atoh_shift);
@@ -1079,6 +1116,10 @@ static int project_host(const uint16_t *czyx, int c, int z, int y, int x, int zl
 
 static int check_binned(int method, int bin)
 {
+    if (method >= 0 && (method & TIP_PROJECT_MANIFOLD)) {
+        if (bin != 1) return fail(TIP_ERR_UNSUPPORTED, "projection: build_manifold with bin_size %d (bin_size 1 supported)", bin);
+        method &= ~TIP_PROJECT_MANIFOLD;
+    }
     if (method < 0 || method > 2) return fail(TIP_ERR_ARG, "projection: method %d (0 max_averages, 1 max_std, 2 multi_channel)", method);
     if (bin < 1 || bin > 128) return fail(TIP_ERR_UNSUPPORTED, "projection: bin_size %d (1..128 supported)", bin);
     return TIP_OK;
@@ -1137,6 +1178,31 @@ int tip_project_u16_binned(const uint16_t *czyx, int c, int z, int y, int x, int
     int rc = check_binned(method, bin_size);
     if (rc) return rc;
     return project_host(czyx, c, z, y, x, zlo, zhi, min_z, ref_ch, method, bin_size, airyscan, atoh_shift, t05, t1, t2, t30, proj, zmap);
+}
+
+// sp.py:87-165 on its own: score float32 (z, y, x) host -> int64 (y, x) plane map
+int tip_build_manifold_f32(const float *score, int z, int y, int x, int64_t *chosen)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!score || !chosen || z < 1 || y < 1 || x < 1) return fail(TIP_ERR_ARG, "tip_build_manifold_f32: bad arguments");
+    const size_t P = (size_t)y * x, V = P * z;
+    WsGuard ws;
+    float *ds = ws.get<float>(V);
+    int *bz = ws.get<int>(P), *err = ws.get<int>(1);
+    if (!ds || !bz || !err) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(ds, score, V * 4, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipMemsetAsync(err, 0, sizeof(int), c.stream));
+    int rc = manifold_dev(ds, z, y, x, bz, err);
+    if (rc) return rc;
+    std::vector<int> hb(P);
+    int herr = 0;
+    TIP_HIP(hipMemcpyAsync(hb.data(), bz, P * 4, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    if (herr) return fail(TIP_ERR_HIP, "build_manifold: a pixel without a visited neighbour (upstream raises TypeError here)");
+    for (size_t i = 0; i < P; ++i) chosen[i] = hb[i];
+    return TIP_OK;
 }
 
 }  // extern "C"

@@ -4,10 +4,11 @@ movie / large-image drivers around it (sp.py:168-316).
 Signature, defaults, return types and error behaviour follow the reference; the arithmetic runs in
 libtissue_hip.so (tip_project_u16 / tip_project_u16_binned).  Covered: bin_size == 1 (what every BASELINE config and
 movie_surface_projection's default use) and bin_size > 1 with methods 'max_averages', 'max_std', 'multi_channel'
-(sp.py:39-65); build_manifold (the serial spiral of sp.py:87-165) is not.
+(sp.py:39-65), and build_manifold (the spiral of sp.py:87-165, as a scan of function tables on the device) with bin_size 1.
 """
 
 _METHODS = {"max_averages": 0, "max_std": 1, "multi_channel": 2}
+_MANIFOLD = 16                 # TIP_PROJECT_MANIFOLD (include/tissue_hip.h)
 import ctypes
 
 import numpy as np
@@ -21,8 +22,8 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
                                   build_manifold=False):
     if bin_size > 1 and method not in ("max_averages", "max_std", "multi_channel"):
         raise TypeError("exceptions must derive from BaseException")  # sp.py:53 raises a str
-    if build_manifold:
-        raise NotImplementedError("MI355X path covers build_manifold=False (SURVEY.md 8f rank 3)")
+    if build_manifold and bin_size > 1:
+        raise NotImplementedError("MI355X path covers build_manifold with bin_size 1")
     if bin_size > 128:
         raise NotImplementedError("MI355X path covers bin_size <= 128")
     if axes.find("T") >= 0:
@@ -54,9 +55,9 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
     proj = np.empty((C, Y, X), np.float64)
     zmap = np.empty((Y, X), np.int64)
     lib = _lib.lib()
-    if bin_size > 1:
+    if bin_size > 1 or build_manifold:
         rc = lib.tip_project_u16_binned(_lib.ptr(image), C, Z, Y, X, int(zlo), int(zhi), int(min_z), int(reference_channel),
-                                        _METHODS[method], int(bin_size), 1 if airyscan else 0, int(atoh_shift),
+                                        (_METHODS[method] if bin_size > 1 else 0) | (_MANIFOLD if build_manifold else 0), int(bin_size), 1 if airyscan else 0, int(atoh_shift),
                                         _lib.ptr(t05), _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(t30), _lib.ptr(proj),
                                         _lib.ptr(zmap))
     else:
@@ -67,6 +68,17 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
     if z_map:
         return proj, zmap
     return proj
+
+
+def build_continues_manifold(score):
+    """sp.py:87-165: the z-map grown as a square spiral around the score's global maximum (int64, like upstream's
+    astype(int)); on the device a scan of per-pixel function tables along every straight run of a ring (tip_manifold.h)."""
+    s = np.ascontiguousarray(score, dtype=np.float32)
+    if s.ndim != 3:
+        raise ValueError("build_continues_manifold takes a (Z, Y, X) score")
+    out = np.empty(s.shape[1:], np.int64)
+    _lib.check(_lib.lib().tip_build_manifold_f32(_lib.ptr(s), s.shape[0], s.shape[1], s.shape[2], _lib.ptr(out)))
+    return out
 
 
 # ---- drivers (sp.py:168-316): whole movies / large images through the per-time-point projection -----------------------------

@@ -718,6 +718,35 @@ def gold_seg():
     save("seg", **out)
 
 
+def gold_manifold():
+    """build_continues_manifold (sp.py:87-165) on small scores: start in the middle, in a corner, on an edge, a frame so
+    short that row 0's "up" neighbour (Python index -1 = the last row) is already visited, and the full projection with
+    build_manifold=True (atoh shift, min_z / max_z)."""
+    rng = np.random.default_rng(500)
+    out = {}
+    def smooth(Z, R, C, seed):
+        r = np.random.default_rng(seed)
+        s = r.random((Z, R, C)).astype(np.float32)
+        s = ndi.gaussian_filter(s, (0.7, 2.0, 2.0), mode="nearest").astype(np.float32)
+        return s
+    cases = {"mid": smooth(7, 23, 31, 1), "tall": smooth(5, 40, 9, 2), "flat": smooth(9, 4, 37, 3), "two": smooth(4, 2, 11, 4),
+             "one": smooth(6, 1, 17, 5), "big": smooth(12, 70, 66, 6)}
+    corner = smooth(6, 19, 21, 7); corner[3, 0, 0] = 10.0
+    edge = smooth(6, 18, 25, 8); edge[2, 17, 12] = 10.0
+    mid = smooth(8, 21, 21, 9); mid[5, 10, 10] = 10.0           # start row exactly in the middle: rows 0 and R-1 on the same ring
+    cases.update(corner=corner, edge=edge, centre=mid)
+    for k, sc in cases.items():
+        out["m_%s_score" % k] = sc
+        out["m_%s_z" % k] = sp.build_continues_manifold(sc)
+    st = synthetic.make_stack(10, 48, 56, seed=510)
+    proj, zmap = sp.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, z_map=True, build_manifold=True)
+    out.update(p_stack=st, p_proj=proj, p_zmap=zmap)
+    proj2, zmap2 = sp.time_point_surface_projection(st.copy(), "CZYX", 1, min_z=1, max_z=9, airyscan=False, z_map=True,
+                                                    build_manifold=True, atoh_shift=-1)
+    out.update(p2_proj=proj2, p2_zmap=zmap2)
+    save("manifold", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gold_weights()
@@ -737,4 +766,5 @@ if __name__ == "__main__":
     gold_drift()
     gold_drivers()
     gold_seg()
+    gold_manifold()
     print("done")
