@@ -52,6 +52,8 @@ TIP_API int tip_free(void *dptr);
 TIP_API int tip_memcpy_h2d(void *dst, const void *src, size_t bytes);
 TIP_API int tip_memcpy_d2h(void *dst, const void *src, size_t bytes);
 TIP_API int tip_memcpy_d2d(void *dst, const void *src, size_t bytes);   /* asynchronous, calling thread's stream */
+/* a (height x width_bytes) block between pitched device buffers: the windows of the local-drift map (ti.py:2152-2166) */
+TIP_API int tip_memcpy2d_d2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t height);
 TIP_API int tip_memset(void *dst, int value, size_t bytes);
 TIP_API int tip_sync(void);                       /* wait for this thread's stream */
 

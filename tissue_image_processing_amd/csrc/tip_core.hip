@@ -248,6 +248,17 @@ int tip_memcpy_d2d(void *dst, const void *src, size_t bytes)   // asynchronous o
     return TIP_OK;
 }
 
+// 2-D block copy on the device (a window of a frame into a contiguous buffer): pitches and width in bytes
+int tip_memcpy2d_d2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t height)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!dst || !src || width_bytes > dst_pitch || width_bytes > src_pitch) return fail(TIP_ERR_ARG, "tip_memcpy2d_d2d: bad arguments");
+    if (width_bytes == 0 || height == 0) return TIP_OK;
+    TIP_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, hipMemcpyDeviceToDevice, c.stream));
+    return TIP_OK;
+}
+
 int tip_memset(void *dst, int value, size_t bytes)
 {
     Ctx &c = ctx();

@@ -78,6 +78,23 @@ def change_type(current_type, type_index, is_positive):
     return out.astype(np.uint8)
 
 
+def _link_two_frames(f, search_range, adaptive_stop, pos_columns, t_column, memory, neighbor_strategy, dist_func):
+    """trackpy.link's call signature over linking.FrameLinker for a two-frame table (parity with trackpy unpinned, see
+    linking.py): rows of the first frame get particles 0..n-1 in row order, rows of the second the particle of their
+    partner or fresh numbers."""
+    from .linking import FrameLinker, embed
+    out = f.copy()
+    frames = np.sort(f[t_column].unique())
+    linker = FrameLinker(search_range=search_range, adaptive_stop=adaptive_stop, memory=memory)
+    particle = np.zeros(len(f), np.int64)
+    for t in frames:
+        rows = np.flatnonzero(f[t_column].to_numpy() == t)
+        feats = [f[c].to_numpy()[rows] for c in pos_columns]           # (cy, cx, area)
+        particle[rows] = linker.link(embed(feats[0], feats[1], feats[2]))
+    out["particle"] = particle
+    return out
+
+
 class TissueHipMixin(object):
     """Hot methods of Tissue; expects the host class to provide get_labels / get_cells_info / set_cells_info /
     get_cell_types / set_cell_types, max_cell_area, min_cell_area, type_names, drifts, valid_frames,
@@ -410,6 +427,116 @@ class TissueHipMixin(object):
         self.drifts[frame - 1, 0] = shift_y
         self.drifts[frame - 1, 1] = shift_x
         return shift_y, shift_x
+
+    # ---- re-linking one frame pair with local drifts (ti.py:2115-2246) ---------------------------------------------------
+    def get_cell_id_by_position(self, frame, pos):
+        """ti.py:475-488: the track id of the cell under pixel (x, y)."""
+        labels, table = self.get_labels(frame), self.get_cells_info(frame)
+        if labels is None or table is None:
+            return 0
+        x, y = pos
+        row = labels[y, x] - 1
+        if row < 0:
+            return 0
+        try:
+            return table.label[row]
+        except (IndexError, KeyError):
+            return 0
+
+    def get_cell_centroid_by_id(self, frame, id):
+        """ti.py:491-498."""
+        cell = self.get_cells_info(frame).query("label == %d and valid == 1 and empty_cell == 0" % id)
+        if cell.shape[0] < 1:
+            return None
+        return cell.cx.values[0], cell.cy.values[0]
+
+    def fix_one_frame_tracking_using_local_drifts(self, start_frame, end_frame, images, step_size=100, window_size=700,
+                                                  image_in_memory=False, start_frame_pos=None, end_frame_pos=None, link=None):
+        """ti.py:2115-2246: re-link end_frame (which must be the first valid frame after start_frame) to start_frame after
+        moving start_frame's centroids by a LOCAL drift map -- the mean refined drift of the sliding windows over each
+        centroid, every window through the device phase correlation (_registration.local_drifts) -- then carry the new
+        track ids through the frames that follow with a running old -> new table.  `link` stands in for trackpy.link
+        (same call signature; default: the linker of linking.py behind that signature, parity unpinned like T1)."""
+        from ._registration import local_drifts, sample_local_drift
+        next_frame = -1
+        for frame in range(start_frame + 1, self.number_of_frames):          # (the last frame is never a candidate, as upstream)
+            if self.valid_frames[frame - 1] == 1:
+                next_frame = frame
+                break
+        if next_frame < 0 or next_frame != end_frame:
+            return 0
+        stage = getattr(self, "stage_locations", None)
+        if start_frame_pos is not None and end_frame_pos is not None:
+            a = self.get_cell_centroid_by_id(start_frame, self.get_cell_id_by_position(start_frame, start_frame_pos))
+            b = self.get_cell_centroid_by_id(end_frame, self.get_cell_id_by_position(end_frame, end_frame_pos))
+            shift = (b[1] - a[1], b[0] - a[0])
+        elif stage is not None:
+            shift = (stage.loc[next_frame - 1, ["z", "y", "x"]].to_numpy() - stage.loc[start_frame - 1, ["z", "y", "x"]].to_numpy()) / \
+                stage.loc[frame - 1, ["physical_size_z", "physical_size_y", "physical_size_x"]].to_numpy()
+        else:
+            shift = (0, 0)
+        first_image, second_image = images[start_frame - 1], images[next_frame - 1]
+        if not image_in_memory:
+            first_image, second_image = first_image.compute(), second_image.compute()
+        keep = "valid == 1 and empty_cell == 0"
+        first = self.get_cells_info(start_frame).query(keep)
+        cx, cy = np.copy(first.cx.to_numpy()), np.copy(first.cy.to_numpy())
+        # x / y are swapped between the stage table and the image, and the map is read at [cx, cy], as upstream
+        drifts = local_drifts(first_image, second_image, shift[-2], shift[-1], step_size, window_size)
+        rows, cols = np.round(cx).astype(int), np.round(cy).astype(int)
+        H, W = np.shape(first_image)
+        if rows.size and (rows.max() >= H or cols.max() >= W):
+            raise IndexError("index %d is out of bounds for the %dx%d drift map" % (max(rows.max(), cols.max()), H, W))
+        dx, dy = sample_local_drift(drifts, rows, cols)
+        cx -= dx
+        cy -= dy
+        first_tab = pd.DataFrame({"cx": cx, "cy": cy, "area": np.copy(first.area.to_numpy()), "frame_index": np.zeros(cx.shape),
+                                  "label": np.copy(first.label.to_numpy())}, index=first.index)
+        second_info = self.get_cells_info(next_frame)
+        second = second_info.query(keep)
+        second_tab = pd.DataFrame({"cx": second.cx.to_numpy(), "cy": second.cy.to_numpy(), "area": np.copy(second.area.to_numpy()),
+                                   "frame_index": np.ones((second.shape[0],)), "label": np.copy(second.label.to_numpy())},
+                                  index=second.index)
+        if link is None:
+            link = _link_two_frames
+        linked = link(pd.concat([first_tab, second_tab]), search_range=100, adaptive_stop=10, pos_columns=["cy", "cx", "area"],
+                      t_column="frame_index", memory=0, neighbor_strategy='BTree', dist_func=self.tracking_dist_func)
+        first_ids = linked.query("frame_index == 0").label.to_numpy()
+        second_linked = linked.query("frame_index == 1")
+        particles = second_linked.particle.to_numpy()
+        old_ids = second_linked.label.to_numpy()
+        new_ids = np.copy(old_ids)
+        # linked cells take the id of their partner in start_frame; unlinked cells whose id also lives in start_frame were
+        # linked before and are not any more: fresh ids; the other unlinked cells keep theirs
+        is_linked = particles < first_ids.size
+        new_ids[is_linked] = first_ids[particles[is_linked]]
+        stale = np.logical_and(~is_linked, np.isin(new_ids, first_ids))
+        free = max(np.max(first_ids), np.max(new_ids)) + 1
+        new_ids[stale] = np.arange(free, free + int(stale.sum()))
+        second_info.loc[second_linked.index.to_numpy(), "label"] = new_ids
+        # ids of start_frame that neither appear in end_frame nor were handed out keep their meaning (a cell may skip a frame)
+        skipping = first_ids[np.logical_and(~np.isin(first_ids, old_ids, assume_unique=True),
+                                            ~np.isin(first_ids, new_ids, assume_unique=True))]
+        old_ids, new_ids = np.hstack([old_ids, skipping]), np.hstack([new_ids, skipping])
+        for frame in range(next_frame + 1, self.number_of_frames):
+            if self.valid_frames[frame - 1] != 1:
+                continue
+            info = self.get_cells_info(frame)
+            cells = info.query(keep)
+            ids = cells.label.to_numpy()
+            known = np.isin(ids, old_ids, assume_unique=True)
+            taken = np.isin(ids, new_ids, assume_unique=True)
+            untouched = np.logical_and(~known, ~taken)          # neither renamed nor colliding: maps to itself
+            old_ids, new_ids = np.hstack([old_ids, ids[untouched]]), np.hstack([new_ids, ids[untouched]])
+            clash = np.logical_and(~known, taken)               # an id that now means another cell: fresh ids
+            free = max(np.max(old_ids), np.max(new_ids)) + 1
+            old_ids = np.hstack([old_ids, ids[clash]])
+            new_ids = np.hstack([new_ids, np.arange(free, free + int(clash.sum()))])
+            used = np.isin(old_ids, ids, assume_unique=True)
+            by_key = np.argsort(old_ids[used])
+            by_id = np.argsort(ids)
+            info.loc[cells.index.to_numpy()[by_id], "label"] = new_ids[used][by_key]
+        return 0
 
     # ---- T4 -------------------------------------------------------------------------------------------------
     def get_trackking_labels(self, frame):

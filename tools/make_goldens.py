@@ -747,6 +747,91 @@ def gold_manifold():
     save("manifold", **out)
 
 
+def gold_local_drifts():
+    """fix_one_frame_tracking_using_local_drifts (ti.py:2115-2246) with trackpy.link replaced by a deterministic stand-in
+    that RECORDS the table it is given: pins (a) the drift-corrected centroids, i.e. the local-drift map of ti.py:2149-2175
+    sampled at the cells, and (b) the label bookkeeping of the frames that follow, given the stand-in's links."""
+    import pandas as pd
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(610)
+    H, W, frames = 216, 216, 5          # (square: upstream indexes the drift map [cx, cy], i.e. x as the row)
+    base = ndi.gaussian_filter(rng.random((H + 40, W + 40)), 2.5) * 4000
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    imgs = []
+    for t in range(frames):
+        # frame t: the base texture under a smooth, spatially varying displacement that grows with t
+        dy = 1.7 * t + 1.5 * t * np.sin(xx / 60.0)
+        dx = -1.1 * t + 1.2 * t * np.cos(yy / 50.0)
+        imgs.append(np.round(map_coordinates(base, [yy + 20 + dy, xx + 20 + dx], order=1)).astype(np.uint16))
+    images = np.stack(imgs)
+    # label maps: a jittered grid of square cells, the same cells in every frame (ids permuted per frame)
+    labs, tmp = [], tempfile.mkdtemp(prefix="tipgold_")
+    t = ti.Tissue(frames, os.path.join(tmp, "movie_l"), ["zo"], load_to_memory=True)
+    for f in range(frames):
+        lab = np.zeros((H, W), np.int32)
+        k = 0
+        for r in range(6, H - 14, 16):
+            for c in range(6, W - 14, 16):
+                k += 1
+                lab[r + (f % 2):r + 12, c:c + 12 - (f % 3 == 1)] = k
+                lab[r + 12, c + (k + f) % 9] = k               # one extra pixel: fractional centroids
+        labs.append(lab)
+        t.set_labels(f + 1, lab.copy(), reset_data=True)
+        t.calculate_frame_cellinfo(f + 1)
+        ci = t.get_cells_info(f + 1)
+        n = ci.shape[0]
+        perm = np.random.default_rng(620 + f).permutation(n) + 1 + 3 * f      # track ids differ between frames
+        ci.loc[:, "label"] = perm
+        if f == 3:
+            ci.loc[5, "valid"] = 0
+    t.valid_frames[2] = 1
+    recorded = {}
+
+    def fake_link(f, search_range, adaptive_stop, pos_columns, t_column, memory, neighbor_strategy, dist_func):
+        recorded["table"] = f.copy()
+        recorded["args"] = (search_range, adaptive_stop, tuple(pos_columns), t_column, memory, neighbor_strategy)
+        a = f[f[t_column] == 0]
+        b = f[f[t_column] == 1]
+        out = f.copy()
+        part = np.zeros(len(f), np.int64)
+        part[:len(a)] = np.arange(len(a))
+        used, nxt = set(), len(a)
+        ax, ay = a.cx.to_numpy(), a.cy.to_numpy()
+        for j, (bx, by) in enumerate(zip(b.cx.to_numpy(), b.cy.to_numpy())):
+            d2 = (ax - bx) ** 2 + (ay - by) ** 2
+            i = int(np.argmin(d2))
+            if d2[i] < 36.0 and i not in used and j % 7 != 3:       # every 7th cell stays unlinked on purpose
+                used.add(i); part[len(a) + j] = i
+            else:
+                part[len(a) + j] = nxt; nxt += 1
+        out["particle"] = part
+        return out
+
+    ti.trackpy = _NS(link=fake_link)
+    before = [t.get_cells_info(f + 1).label.to_numpy().copy() for f in range(frames)]
+    rc = t.fix_one_frame_tracking_using_local_drifts(2, 3, images, step_size=24, window_size=64, image_in_memory=True)
+    after = [t.get_cells_info(f + 1).label.to_numpy().copy() for f in range(frames)]
+    tab = recorded["table"]
+    out = {"images": images, "rc": np.array(rc), "link_cx": tab.cx.to_numpy(), "link_cy": tab.cy.to_numpy(),
+           "link_area": tab.area.to_numpy(), "link_frame": tab.frame_index.to_numpy(), "link_label": tab.label.to_numpy(),
+           "link_index": tab.index.to_numpy(), "link_args": np.array([str(v) for v in recorded["args"]])}
+    for f in range(frames):
+        out["labels_%d" % f] = labs[f]
+        out["ids_before_%d" % f] = before[f]
+        out["ids_after_%d" % f] = after[f]
+        out["valid_%d" % f] = t.get_cells_info(f + 1).valid.to_numpy()
+    # the same with a coarse initial shift given by two clicked positions (start_frame_pos / end_frame_pos are (x, y))
+    for f in range(frames):
+        t.get_cells_info(f + 1).loc[:, "label"] = before[f]
+    rc2 = t.fix_one_frame_tracking_using_local_drifts(2, 3, images, step_size=30, window_size=80, image_in_memory=True,
+                                                      start_frame_pos=(60, 45), end_frame_pos=(62, 42))
+    tab = recorded["table"]
+    out.update(rc2=np.array(rc2), link2_cx=tab.cx.to_numpy(), link2_cy=tab.cy.to_numpy())
+    for f in range(frames):
+        out["ids_after2_%d" % f] = t.get_cells_info(f + 1).label.to_numpy().copy()
+    save("local_drifts", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gold_weights()
@@ -767,4 +852,5 @@ if __name__ == "__main__":
     gold_drivers()
     gold_seg()
     gold_manifold()
+    gold_local_drifts()
     print("done")
