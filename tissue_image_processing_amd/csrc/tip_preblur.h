@@ -22,7 +22,9 @@ constexpr int PB_Y = 32, PB_X = 128, PB_H = 4, PB_T = 1024, PB_O = 4;   // 1024 
 //  the four separate kernels 0.78 ms)
 struct ShortTaps { double w[8]; };    // the first radius + 1 taps of a Taps (two full Taps would not fit the 4 KB kernel-argument segment)
 constexpr int PB_WY = PB_Y + 2 * PB_H, PB_WX = PB_X + 2 * PB_H;       // padded tile: 40 x 136
-constexpr int PB_OWN = (PB_WY * PB_WX + PB_T - 1) / PB_T;             // padded-tile pixels per thread (11)
+constexpr int PB_OWN = (PB_WY * PB_WX + PB_T - 1) / PB_T;             // padded-tile pixels per thread (6)
+constexpr int PB_YI = PB_WX * (PB_Y / 4);                             // y-pass work items (column, 4-row segment): 1088
+static_assert(PB_YI >= PB_T && (PB_YI - PB_T) * 4 <= PB_T, "y-pass work split");
 
 __global__ void __launch_bounds__(PB_T) k_preblur_fused(const uint16_t *__restrict__ src, int airy, const float *__restrict__ clip_p95,
                                                         const int *__restrict__ clip_has, float *__restrict__ out, int Z, int Y, int X,
@@ -49,91 +51,108 @@ __global__ void __launch_bounds__(PB_T) k_preblur_fused(const uint16_t *__restri
         if (has && v > cp) v = cp;
         return v;
     };
-    // first z pass: raw window (planes z-2 .. z+2 of the plane being produced), 'nearest' at both ends
+    // Both z windows are RINGS indexed by plane % 5 and the plane loop is unrolled five-fold, so that every ring index is a
+    // compile-time constant: no window shifting (the shifts were 142 of the loop's ~700 instructions, and the kernel is
+    // bound by instruction issue).
+    // first z pass: raw values of planes z-2 .. z+2 around the plane being produced, 'nearest' at both ends
     float w[PB_OWN][5];      // (float32: windows in double cost registers and with them occupancy -- measured 1.8x slower)
 #pragma unroll
     for (int k = 0; k < PB_OWN; ++k) {
         if (off[k] < 0) continue;
         const float a = raw(0, k);
-        w[k][0] = w[k][1] = w[k][2] = a;
-        w[k][3] = raw(min(1, Z - 1), k);
-        w[k][4] = raw(min(2, Z - 1), k);
+        w[k][3] = w[k][4] = w[k][0] = a;          // planes -2, -1, 0
+        w[k][1] = raw(min(1, Z - 1), k);
+        w[k][2] = raw(min(2, Z - 1), k);
     }
-    // second z pass: window [A(zo-2) .. A(zo+2)] of x-pass output planes for this thread's 8 output pixels (row oy, columns
-    // ox .. ox+7), 'nearest' at both ends exactly like the first one: starts as [A0, A0, A0, A1, A2], then slides
+    // second z pass: x-pass output planes zo-2 .. zo+2 of this thread's PB_O output pixels (row oy, columns ox ..), same rule
     const int oy = t / (PB_X / PB_O), ox = (t % (PB_X / PB_O)) * PB_O;
     float ring[5][PB_O], last[PB_O];
-    for (int zp = 0; zp < Z + 2; ++zp) {      // zp < Z: plane zp goes through the in-plane passes; output plane zp - 2 follows
-        if (zp < Z) {
+    for (int zp0 = 0; zp0 < Z + 2; zp0 += 5) {
 #pragma unroll
-            for (int k = 0; k < PB_OWN; ++k) {
-                if (off[k] < 0) continue;
-                const int i = t + k * PB_T;
-                double tmp = (double)w[k][2] * k05.w[2];
-                tmp += ((double)w[k][0] + (double)w[k][4]) * k05.w[0];
-                tmp += ((double)w[k][1] + (double)w[k][3]) * k05.w[1];
-                (&p1[0][0])[i] = (float)tmp;
-                w[k][0] = w[k][1]; w[k][1] = w[k][2]; w[k][2] = w[k][3]; w[k][3] = w[k][4];
-                w[k][4] = raw(min(zp + 3, Z - 1), k);
-            }
-        }
-        __syncthreads();
-        if (zp < Z) {
-            // y pass: work item = (column, 4-row segment); 136 columns x (PB_Y / 4) segments
-            for (int item = t; item < PB_WX * (PB_Y / 4); item += PB_T) {
-                const int yc = item % PB_WX, yr = (item / PB_WX) * 4;
-                double win[12];
+        for (int u = 0; u < 5; ++u) {             // zp % 5 == u
+            const int zp = zp0 + u;               // zp < Z: plane zp goes through the in-plane passes; output plane zp - 2 follows
+            if (zp >= Z + 2) break;               // (uniform)
+            if (zp < Z) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) win[i] = (double)p1[yr + i][yc];
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    double tmp = win[o + 4] * k1.w[4];
-#pragma unroll
-                    for (int d = 4; d >= 1; --d) tmp += (win[o + 4 - d] + win[o + 4 + d]) * k1.w[4 - d];
-                    yb[yr + o][yc] = (float)tmp;
+                for (int k = 0; k < PB_OWN; ++k) {
+                    if (off[k] < 0) continue;
+                    const int i = t + k * PB_T;
+                    double tmp = (double)w[k][u] * k05.w[2];
+                    tmp += ((double)w[k][(u + 3) % 5] + (double)w[k][(u + 2) % 5]) * k05.w[0];
+                    tmp += ((double)w[k][(u + 4) % 5] + (double)w[k][(u + 1) % 5]) * k05.w[1];
+                    (&p1[0][0])[i] = (float)tmp;
+                    w[k][(u + 3) % 5] = raw(min(zp + 3, Z - 1), k);      // plane zp + 3 takes the slot of plane zp - 2
                 }
             }
-        }
-        __syncthreads();
-        if (zp < Z) {                                                           // x pass: PB_O outputs from PB_O + 8 inputs
-            float v[PB_O + 8];
+            __syncthreads();
+            if (zp < Z) {
+                // y pass: work item = (column, 4-row segment); 136 columns x (PB_Y / 4) segments = 1088 items for 1024
+                // threads: the first 1024 go one per thread, the last 64 are split into single outputs over 256 threads
+                // (a second whole item for one wave made every other wave wait for it at the barrier)
+                {
+                    const int yc = t % PB_WX, yr = (t / PB_WX) * 4;
+                    double win[12];
 #pragma unroll
-            for (int i = 0; i < (PB_O + 8) / 4; ++i) {
-                const float4 f = *reinterpret_cast<const float4 *>(&yb[oy][ox + 4 * i]);
-                v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                    for (int i = 0; i < 12; ++i) win[i] = (double)p1[yr + i][yc];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        double tmp = win[o + 4] * k1.w[4];
+#pragma unroll
+                        for (int d = 4; d >= 1; --d) tmp += (win[o + 4 - d] + win[o + 4 + d]) * k1.w[4 - d];
+                        yb[yr + o][yc] = (float)tmp;
+                    }
+                }
+                if (t < (PB_YI - PB_T) * 4) {
+                    const int item = PB_T + (t >> 2), o = t & 3;
+                    const int yc = item % PB_WX, yr = (item / PB_WX) * 4 + o;
+                    double win[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) win[i] = (double)p1[yr + i][yc];
+                    double tmp = win[4] * k1.w[4];
+#pragma unroll
+                    for (int d = 4; d >= 1; --d) tmp += (win[4 - d] + win[4 + d]) * k1.w[4 - d];
+                    yb[yr][yc] = (float)tmp;
+                }
             }
+            __syncthreads();
+            if (zp < Z) {                                                           // x pass: PB_O outputs from PB_O + 8 inputs
+                float v[PB_O + 8];
+#pragma unroll
+                for (int i = 0; i < (PB_O + 8) / 4; ++i) {
+                    const float4 f = *reinterpret_cast<const float4 *>(&yb[oy][ox + 4 * i]);
+                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                }
+#pragma unroll
+                for (int k = 0; k < PB_O; ++k) {
+                    double tmp = (double)v[k + 4] * k1.w[4];
+#pragma unroll
+                    for (int d = 4; d >= 1; --d) tmp += ((double)v[k + 4 - d] + (double)v[k + 4 + d]) * k1.w[4 - d];
+                    last[k] = (float)tmp;
+                }
+            }   // (zp >= Z: `last` keeps the last plane: the window's far end is replicated)
 #pragma unroll
             for (int k = 0; k < PB_O; ++k) {
-                double tmp = (double)v[k + 4] * k1.w[4];
-#pragma unroll
-                for (int d = 4; d >= 1; --d) tmp += ((double)v[k + 4 - d] + (double)v[k + 4 + d]) * k1.w[4 - d];
-                last[k] = (float)tmp;
+                ring[u][k] = last[k];
+                if (zp == 0) ring[3][k] = ring[4][k] = last[k];                 // planes -2, -1
             }
-        }   // (zp >= Z: `last` keeps the last plane: the window's far end is replicated)
+            const int zo = zp - 2;
+            if (zo >= 0 && y0 + oy < Y && x0 + ox < X) {
+                float o[PB_O];
 #pragma unroll
-        for (int k = 0; k < PB_O; ++k) {
-            if (zp == 0) ring[0][k] = ring[1][k] = ring[2][k] = last[k];
-            else if (zp == 1) ring[3][k] = last[k];
-            else if (zp == 2) ring[4][k] = last[k];
-            else { ring[0][k] = ring[1][k]; ring[1][k] = ring[2][k]; ring[2][k] = ring[3][k]; ring[3][k] = ring[4][k]; ring[4][k] = last[k]; }
-        }
-        const int zo = zp - 2;
-        if (zo >= 0 && y0 + oy < Y && x0 + ox < X) {
-            float o[PB_O];
+                for (int k = 0; k < PB_O; ++k) {                                // window: planes zo-2 .. zo+2 = slots u+1 .. u+4, u
+                    double tmp = (double)ring[(u + 3) % 5][k] * k05.w[2];
+                    tmp += ((double)ring[(u + 1) % 5][k] + (double)ring[u][k]) * k05.w[0];
+                    tmp += ((double)ring[(u + 2) % 5][k] + (double)ring[(u + 4) % 5][k]) * k05.w[1];
+                    o[k] = (float)tmp;
+                }
+                float *dst = out + (long)zo * P + (long)(y0 + oy) * X + x0 + ox;
+                if (x0 + ox + PB_O <= X && (X & 3) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
 #pragma unroll
-            for (int k = 0; k < PB_O; ++k) {
-                double tmp = (double)ring[2][k] * k05.w[2];
-                tmp += ((double)ring[0][k] + (double)ring[4][k]) * k05.w[0];
-                tmp += ((double)ring[1][k] + (double)ring[3][k]) * k05.w[1];
-                o[k] = (float)tmp;
-            }
-            float *dst = out + (long)zo * P + (long)(y0 + oy) * X + x0 + ox;
-            if (x0 + ox + PB_O <= X && (X & 3) == 0) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < PB_O; ++k)
-                    if (x0 + ox + k < X) dst[k] = o[k];
+                    for (int k = 0; k < PB_O; ++k)
+                        if (x0 + ox + k < X) dst[k] = o[k];
+                }
             }
         }
     }

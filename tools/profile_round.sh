@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/su -o su -- python3
 echo "stats unet done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pm -o pm -- python3 bench.py --workload unet --steps 1 --warmup 1 --no-cpu-baseline > $out/pm.json 2> $out/pm.err || exit 1
 echo "pmc mfma done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/ps -o ps -- python3 bench.py --workload projection --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/ps.json 2> $out/ps.err || exit 1
+echo "pmc mfma (score passes) done"
 cp $(find $out/s1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_inflight1.csv
 cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_default_inflight4.csv
 cp $(find $out/su -name "*kernel_stats.csv" | head -1) $out/${tag}_unet_kernel_stats.csv
@@ -35,8 +37,9 @@ keep = [r for r in body if not r[ki].startswith("__amd")]
 csv.writer(open(sys.argv[2], "w")).writerows([hdr] + keep)
 PY
 done
-# MFMA utilisation of the U-Net's kernels: busy cycles of the matrix pipe / busy CU cycles, per kernel (summed over launches)
-python3 - "$(find $out/pm -name '*counter_collection.csv' | head -1)" "$out/${tag}_unet_mfma_busy.json" <<'PY'
+# MFMA utilisation: busy cycles of the matrix pipe / busy CU cycles, per kernel (summed over launches) -- the U-Net's kernels
+# and the projection's score passes
+cat > $out/mfma_busy.py <<'PY'
 import sys, csv, json, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); calls = collections.defaultdict(int)
 for r in csv.DictReader(open(sys.argv[1])):
@@ -55,5 +58,8 @@ for n in sorted(acc, key=lambda k: -dur[k])[:25]:
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print("wrote", sys.argv[2])
 PY
-rm -rf $out/s1 $out/s3 $out/pf $out/pw $out/su $out/pm
+python3 $out/mfma_busy.py "$(find $out/pm -name '*counter_collection.csv' | head -1)" "$out/${tag}_unet_mfma_busy.json"
+python3 $out/mfma_busy.py "$(find $out/ps -name '*counter_collection.csv' | head -1)" "$out/${tag}_score_mfma_busy.json"
+rm -f $out/mfma_busy.py
+rm -rf $out/s1 $out/s3 $out/pf $out/pw $out/su $out/pm $out/ps
 ls -la $out
