@@ -569,7 +569,8 @@ static int launch_mfma(const float *in, float *out, int Zs, int Y, int X, const 
     const int tiles_pos = cdiv(AXIS == 1 ? Y : X, MF_TO), tiles_ln = cdiv(AXIS == 1 ? X : Y, MF_LN);
     const int ntiles = tiles_pos * tiles_ln * Zs;
     const int cus = cu_count();
-    const int blocks = std::min(ntiles, 2 * cus);       // persistent blocks, two per CU (LDS: 64 KB each)
+    static const int per_cu = getenv("TIP_MFMA_BLOCKS_PER_CU") ? std::max(1, std::min(2, atoi(getenv("TIP_MFMA_BLOCKS_PER_CU")))) : 2;
+    const int blocks = std::min(ntiles, per_cu * cus);  // persistent blocks, two per CU (LDS: 64 KB each); tuning hook: one
     TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, dim3(blocks), dim3(MF_NW * 64), lds, in, out, Zs, Y, X, t, ntiles,
                tiles_pos, tiles_ln);
     return TIP_OK;
