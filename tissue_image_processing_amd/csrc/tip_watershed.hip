@@ -58,6 +58,7 @@ struct WsInfo {           // device-resident scalars
                                      // same-address atomics per launch serialise in L2 (host adds them up)
     unsigned long long fb_v, fb_k;   // fallback reduction
     unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
+    unsigned long long dbg_idle, dbg_certs;               // tile instances that decided nothing / that ran a certificate round
     // endgame results (own words: the tile launches that follow the endgame in the same submission must not clobber them)
     int end_part[64];                // serial commits, spread like changed_part
     int end_oversize, end_unfinished;   // cells of components larger than END_CAP / components whose replay hit the step limit
@@ -195,6 +196,8 @@ constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 //   2.2 - 2.5 ms -- a launch costs in proportion to the cells it evaluates, and fewer resident tiles hide less latency
 constexpr int WS_TILE_DEFAULT = 6, WS_OPEN_A = 6, WS_OPEN_B = 6;
 constexpr int LINE_LAB = -1;
+constexpr int WS_CERT_FROM = 0;         // first tile launch (index within the frame) that may use pocket certificates
+constexpr int WST_STUCK = 0x40000000;   // tile_wst: the tile's last run decided nothing (low bits: undecided cells left in its window)
 // tile-local marker "undecided and already on the work list": label 0 with a non-zero reference field (never leaves LDS)
 constexpr unsigned long long ST_LISTED = 1ULL << 32;
 
@@ -369,7 +372,8 @@ template <int WT, int WS_THREADS, int WH, int WK, int WM = 0, int EV = 0>
 __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X,
                                                   int tilesX, int tilesY, const unsigned char *__restrict__ changed_prev,
                                                   unsigned char *__restrict__ changed_cur, int *__restrict__ tile_und,
-                                                  int *__restrict__ tile_front, int first, int max_rounds, int dbg, WsInfo *info)
+                                                  int *__restrict__ tile_front, int *__restrict__ tile_wst, int first, int max_rounds, int dbg,
+                                                  int allow_certs, WsInfo *info)
 {
     constexpr int WL = WT + 2 * WH;
     constexpr int WE = WT + 2 * WM, E0 = WH - WM, E1 = WL - E0;    // evaluated region: window rows / columns [E0, E1)
@@ -394,6 +398,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
         if (!act) { if (threadIdx.x == 0) changed_cur[tile] = 0; return; }
     }
     const int gy0 = ty * WT - WH, gx0 = tx * WT - WH;
+    int wcount = 0;          // undecided cells in the window at load time
     {   // window load: all state loads of the thread in flight together, then all value loads (the value a labelled
         // cell needs is its pop-time value v[tref]); one wave per tile and few tiles per CU: nothing else hides latency
         constexpr int NLOAD = (WL * WL + WS_THREADS - 1) / WS_THREADS;
@@ -409,6 +414,18 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             lg[u] = in ? gy * X + gx : -1;
             ls[u] = st[in ? lg[u] : 0];
             if (!in) ls[u] = pack_st(LINE_LAB, 0);
+        }
+        // A tile that decided nothing last time -- not even with pocket certificates, which cost ~40 plain rounds -- and is
+        // woken by a neighbour's news can only get further if its OWN window has changed.  Decisions are final, so the
+        // number of undecided cells in the window is an exact change detector: same count, same window, leave at once.
+        if (WS_THREADS == 64 && tile_wst != nullptr) {
+#pragma unroll
+            for (int u = 0; u < NLOAD; ++u) wcount += st_lab(ls[u]) == 0 ? 1 : 0;
+            for (int d = 32; d >= 1; d >>= 1) wcount += __shfl_xor(wcount, d, 64);
+            if (!first && tile_wst[tile] == (wcount | WST_STUCK)) {
+                if (threadIdx.x == 0) changed_cur[tile] = 0;
+                return;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NLOAD; ++u) {
@@ -460,7 +477,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             if (n == 0) {
                 // the list ran dry.  A tile that got nowhere at all tries one round with pocket certificates on its frontier
                 // (they cost ~40 plain rounds; a tile that moved is re-run next launch anyway, with its neighbours' news)
-                if (certs_done || s_chg > 0) break;
+                if (certs_done || s_chg > 0 || !allow_certs) break;
                 __syncthreads();
                 for (int p = threadIdx.x; p < WE * WE; p += WS_THREADS) {
                     const int c = (p / WE + E0) * WL + (p % WE + E0);
@@ -472,6 +489,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
                 }
                 __syncthreads();
                 certs = true; certs_done = true;
+                if (dbg && threadIdx.x == 0) atomicAdd(&info->dbg_certs, 1ULL);
                 n = s_n[cur];
                 if (n == 0) break;
             }
@@ -562,7 +580,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
             if (certs) break;   // nothing moved even with pocket certificates: wait for the neighbours
             // local stall.  Pocket certificates cost ~40 plain rounds, and a tile that has just moved is re-run next launch
             // anyway (with its neighbours' news): only a tile that got nowhere at all tries them.
-            if (chg > 0) break;
+            if (chg > 0 || !allow_certs) break;
             certs = true;
         }
     }
@@ -588,11 +606,13 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     if (threadIdx.x == 0) {
         tile_und[tile] = s_und;
         tile_front[tile] = s_front;
+        if (tile_wst != nullptr) tile_wst[tile] = (wcount - s_chg) | (s_chg == 0 && allow_certs ? WST_STUCK : 0);   // (stuck = certificates tried)
         changed_cur[tile] = s_chg > 0;
         if (s_chg > 0) atomicAdd(&info->changed_part[tile & 63], s_chg);
         if (dbg) {
             atomicAdd(&info->dbg_rounds, (unsigned long long)my_rounds);
             atomicAdd(&info->dbg_tiles, 1ULL);
+            if (s_chg == 0) atomicAdd(&info->dbg_idle, 1ULL);
         }
     }
     if (dbg && my_evals) atomicAdd(&info->dbg_evals, (unsigned long long)my_evals);
@@ -1078,7 +1098,7 @@ __global__ void k_ws_info_init(WsInfo *info)
     info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
-    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
+    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0; info->dbg_idle = 0; info->dbg_certs = 0;
     info->end_oversize = 0; info->end_unfinished = 0; info->ncomp = 0; info->ncells = 0; info->und_total = 0; info->front_total = 0;
     for (int q = 0; q < 64; ++q) info->end_part[q] = 0;
 }
@@ -1116,7 +1136,7 @@ __global__ void k_ws_iter_reset(WsInfo *info)
     info->und_total = 0; info->front_total = 0;
     info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
-    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0;
+    info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0; info->dbg_idle = 0; info->dbg_certs = 0;
 }
 
 int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int32_t *flags_host)
@@ -1244,8 +1264,12 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (!wchg || !wtile_und) return TIP_ERR_NOMEM;
         unsigned char *chg = ws.get<unsigned char>((size_t)2 * ntiles);
         int *tile_und = ws.get<int>((size_t)2 * ntiles);  // [0, ntiles) undecided cells per tile, [ntiles, 2 ntiles) its frontier
-        if (!chg || !tile_und) return TIP_ERR_NOMEM;
+        int *tile_wst = ws.get<int>((size_t)ntiles);
+        if (!chg || !tile_und || !tile_wst) return TIP_ERR_NOMEM;
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
+        TIP_HIP(hipMemsetAsync(tile_wst, 0, (size_t)ntiles * sizeof(int), s));
+        const int cert_from = getenv("TIP_WS_CERT_FROM") ? atoi(getenv("TIP_WS_CERT_FROM")) : WS_CERT_FROM;
+        int *wst_arg = getenv("TIP_WS_NO_SKIP") ? nullptr : tile_wst;     // test hook: re-run stuck tiles on every wake-up
         int iter = 0, fallbacks = 0;
         bool wide = false, wide_after_endgame = false;
         int endgames = 0;
@@ -1260,7 +1284,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         // one launch of the everyday tiles (activity words ping-pong by launch parity; every block writes its word)
         auto tile_launch = [&](int it) -> int {
             unsigned char *prev = chg + (size_t)(it & 1) * ntiles, *cur = chg + (size_t)((it + 1) & 1) * ntiles;
-#define WS_TILE_ARGS img, st, Y, X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, it == 0 ? 1 : 0, 4096, dbg, info
+#define WS_TILE_ARGS img, st, Y, X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, wst_arg, it == 0 ? 1 : 0, 4096, dbg, it >= cert_from ? 1 : 0, info
             switch (variant) {
             case 0: TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, WS_TILE_ARGS); break;
             case 1: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
@@ -1332,7 +1356,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                         if ((rc = tile_launch(iter))) return rc;
                     } else {   // wide pass over every 32x32 tile (own bookkeeping arrays); the everyday tiles recount afterwards
                         TIP_LAUNCH("ws_tiles_wide", (k_ws_tiles<WT_WIDE, WTH_WIDE, WH_WIDE, WK_WIDE>), dim3(wntiles), dim3(WTH_WIDE), 0, img,
-                                   st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, wtile_und + wntiles, 1, 4096, dbg, info);
+                                   st, Y, X, wtilesX, wtilesY, (const unsigned char *)wchg, wchg + wntiles, wtile_und, wtile_und + wntiles, (int *)nullptr, 1, 4096, dbg, 1, info);
                         TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles, 1, ntiles, s));
                     }
                 }
@@ -1343,8 +1367,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             TIP_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
             if (dbg)
-                fprintf(stderr, "ws iter %d %s: tiles %llu rounds %llu evals %llu changed %d undecided %d\n", iter, wide ? "wide" : "fast",
-                        h.dbg_tiles, h.dbg_rounds, h.dbg_evals, h.changed, h.und_total);
+                fprintf(stderr, "ws iter %d %s: tiles %llu (idle %llu, certificate rounds %llu) rounds %llu evals %llu changed %d undecided %d\n",
+                        iter, wide ? "wide" : "fast", h.dbg_tiles, h.dbg_idle, h.dbg_certs, h.dbg_rounds, h.dbg_evals, h.changed, h.und_total);
             if (opening) {
                 if (h.und_total == 0) break;
                 if (h.end_oversize == 0 && h.end_unfinished == 0) break;   // every component was replayed to its end: the rest is unreachable
