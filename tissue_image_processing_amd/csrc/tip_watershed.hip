@@ -193,9 +193,12 @@ constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 //   5  same with the event-driven work list                                       1.45 ms / 18 / 179.4          (8,6)
 //   6  16x16, halo 4, 3-cell evaluated margin, event-driven                        1.49 ms / 14 / 181.6          (6,6)
 //   4  as 6 without the event-driven list 1.58 ms (6,6); margins 5 / 7: 1.83 / 2.67 ms; 32x32 tiles (64, 128, 256 threads):
-//   2.2 - 2.5 ms -- a launch costs in proportion to the cells it evaluates, and fewer resident tiles hide less latency
+//   2.2 - 2.5 ms -- a launch costs in proportion to the cells it evaluates, and fewer resident tiles hide less latency;
+//   8x8 tiles (12 / 13): 1.9 - 2.1 ms (more launches, more halo per interior cell).  Resident tiles per CU matter: padding the
+//   block's LDS so that 10 / 8 / 6 tiles fit instead of 13 (TIP_WS_LDS_PAD) gives 1.70 / 1.83 / 2.19 ms.
 constexpr int WS_TILE_DEFAULT = 6, WS_OPEN_A = 6, WS_OPEN_B = 6;
 constexpr int LINE_LAB = -1;
+constexpr int WS_LDS_PAD = 0;
 constexpr int WS_CERT_FROM = 0;         // first tile launch (index within the frame) that may use pocket certificates
 constexpr int WST_STUCK = 0x40000000;   // tile_wst: the tile's last run decided nothing (low bits: undecided cells left in its window)
 // tile-local marker "undecided and already on the work list": label 0 with a non-zero reference field (never leaves LDS)
@@ -1254,9 +1257,9 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         int variant = WS_TILE_DEFAULT, open_a = WS_OPEN_A, open_b = WS_OPEN_B;
         if (const char *e = getenv("TIP_WS_TILE")) variant = atoi(e);
         if (const char *e = getenv("TIP_WS_OPEN")) sscanf(e, "%d,%d", &open_a, &open_b);
-        if (variant < 0 || variant > 11 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
+        if (variant < 0 || variant > 13 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
             return fail(TIP_ERR_ARG, "watershed: bad TIP_WS_TILE / TIP_WS_OPEN");
-        const int WTv = variant == 3 || variant >= 8 ? 32 : WT_FAST;
+        const int WTv = variant >= 12 ? 8 : (variant == 3 || variant >= 8 ? 32 : WT_FAST);
         const int tilesX = cdiv(X, WTv), tilesY = cdiv(Y, WTv), ntiles = tilesX * tilesY;
         const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
         unsigned char *wchg = ws.get<unsigned char>((size_t)2 * wntiles);
@@ -1269,7 +1272,9 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
         TIP_HIP(hipMemsetAsync(tile_wst, 0, (size_t)ntiles * sizeof(int), s));
         const int cert_from = getenv("TIP_WS_CERT_FROM") ? atoi(getenv("TIP_WS_CERT_FROM")) : WS_CERT_FROM;
-        int *wst_arg = getenv("TIP_WS_NO_SKIP") ? nullptr : tile_wst;     // test hook: re-run stuck tiles on every wake-up
+        int *wst_arg = getenv("TIP_WS_NO_SKIP") ? nullptr : tile_wst;
+        // extra (unused) dynamic LDS per tile block: fewer resident tiles per CU, room for other frames' kernels (tuning hook)
+        const size_t lds_pad = getenv("TIP_WS_LDS_PAD") ? (size_t)atoi(getenv("TIP_WS_LDS_PAD")) : WS_LDS_PAD;     // test hook: re-run stuck tiles on every wake-up
         int iter = 0, fallbacks = 0;
         bool wide = false, wide_after_endgame = false;
         int endgames = 0;
@@ -1286,18 +1291,20 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             unsigned char *prev = chg + (size_t)(it & 1) * ntiles, *cur = chg + (size_t)((it + 1) & 1) * ntiles;
 #define WS_TILE_ARGS img, st, Y, X, tilesX, tilesY, (const unsigned char *)prev, cur, tile_und, tile_und + ntiles, wst_arg, it == 0 ? 1 : 0, 4096, dbg, it >= cert_from ? 1 : 0, info
             switch (variant) {
-            case 0: TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), 0, WS_TILE_ARGS); break;
-            case 1: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 2: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 8, 6, 7>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 3: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7>), dim3(ntiles), dim3(256), 0, WS_TILE_ARGS); break;
-            case 4: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 5: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 6: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 7: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 8: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7, 1>), dim3(ntiles), dim3(256), 0, WS_TILE_ARGS); break;
-            case 9: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
-            case 10: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 128, 3, 6, 0, 1>), dim3(ntiles), dim3(128), 0, WS_TILE_ARGS); break;
-            default: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), 0, WS_TILE_ARGS); break;
+            case 0: TIP_LAUNCH("ws_tiles", (k_ws_tiles<WT_FAST, WTH_FAST, WH_FAST, WK_FAST>), dim3(ntiles), dim3(WTH_FAST), lds_pad, WS_TILE_ARGS); break;
+            case 1: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 2: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 8, 6, 7>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 3: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7>), dim3(ntiles), dim3(256), lds_pad, WS_TILE_ARGS); break;
+            case 4: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 5: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 6: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 7: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 6, 6, 5, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 8: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 256, 8, 6, 7, 1>), dim3(ntiles), dim3(256), lds_pad, WS_TILE_ARGS); break;
+            case 9: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 10: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 128, 3, 6, 0, 1>), dim3(ntiles), dim3(128), lds_pad, WS_TILE_ARGS); break;
+            case 11: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 12: TIP_LAUNCH("ws_tiles", (k_ws_tiles<8, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            default: TIP_LAUNCH("ws_tiles", (k_ws_tiles<8, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
             }
 #undef WS_TILE_ARGS
             return TIP_OK;
