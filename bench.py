@@ -54,7 +54,7 @@ def algorithmic_bytes(kernel, C, Z, Y, X):
 
 
 PMC_NAMES = {  # bench kernel label -> substring of the rocprofv3 kernel name in profiles/r*_pmc_traffic.json
-    "ws_tiles": ("k_ws_tiles<16, 64, 4, 6, 3, 1>", "k_ws_tiles<16, 64, 3, 6"), "score_fast_y": ("k_corr_long_mfma<1", "k_corr_long_mfma2<1", "k_corr_long_fast<1"),
+    "ws_tiles": ("k_ws_tiles<16, 64, 3, 6, 2, 1>", "k_ws_tiles<16, 64, 4, 6, 3, 1>", "k_ws_tiles<16, 64, 3, 6"), "score_fast_y": ("k_corr_long_mfma<1", "k_corr_long_mfma2<1", "k_corr_long_fast<1"),
     "score_fast_x": ("k_corr_long_mfma<2", "k_corr_long_mfma2<2", "k_corr_long_fast<2"),
     "corr_long_y": "k_corr_long_f32<1", "corr_long_x": "k_corr_long_f32<2", "ypass_slide_r4": "k_ypass_slide",
     "xpass_slide_r4": "k_xpass_slide", "zpass_f32_x4": "k_zpass_r2_x4<Src4F32>", "zpass_u16clip_x4": "k_zpass_r2_x4<Src4U16Clip>",

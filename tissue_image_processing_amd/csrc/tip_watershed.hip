@@ -192,11 +192,12 @@ constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 //   0  16x16, halo 3, interior only, every waiting cell re-evaluated each round   1.65 ms / 20 / 172.7 frames/s  (opening 10,8)
 //   5  same with the event-driven work list                                       1.45 ms / 18 / 179.4          (8,6)
 //   6  16x16, halo 4, 3-cell evaluated margin, event-driven                        1.49 ms / 14 / 181.6          (6,6)
+//  14  16x16, halo 3, 2-cell evaluated margin, event-driven (10 KB: 16 tiles / CU)  1.40 ms / 16 / 185.8          (8,6)
 //   4  as 6 without the event-driven list 1.58 ms (6,6); margins 5 / 7: 1.83 / 2.67 ms; 32x32 tiles (64, 128, 256 threads):
 //   2.2 - 2.5 ms -- a launch costs in proportion to the cells it evaluates, and fewer resident tiles hide less latency;
 //   8x8 tiles (12 / 13): 1.9 - 2.1 ms (more launches, more halo per interior cell).  Resident tiles per CU matter: padding the
 //   block's LDS so that 10 / 8 / 6 tiles fit instead of 13 (TIP_WS_LDS_PAD) gives 1.70 / 1.83 / 2.19 ms.
-constexpr int WS_TILE_DEFAULT = 6, WS_OPEN_A = 6, WS_OPEN_B = 6;
+constexpr int WS_TILE_DEFAULT = 14, WS_OPEN_A = 8, WS_OPEN_B = 6;
 constexpr int LINE_LAB = -1;
 constexpr int WS_LDS_PAD = 0;
 constexpr int WS_CERT_FROM = 0;         // first tile launch (index within the frame) that may use pocket certificates
@@ -1257,9 +1258,9 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         int variant = WS_TILE_DEFAULT, open_a = WS_OPEN_A, open_b = WS_OPEN_B;
         if (const char *e = getenv("TIP_WS_TILE")) variant = atoi(e);
         if (const char *e = getenv("TIP_WS_OPEN")) sscanf(e, "%d,%d", &open_a, &open_b);
-        if (variant < 0 || variant > 13 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
+        if (variant < 0 || variant > 15 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
             return fail(TIP_ERR_ARG, "watershed: bad TIP_WS_TILE / TIP_WS_OPEN");
-        const int WTv = variant >= 12 ? 8 : (variant == 3 || variant >= 8 ? 32 : WT_FAST);
+        const int WTv = variant == 12 || variant == 13 ? 8 : (variant == 3 || (variant >= 8 && variant <= 11) ? 32 : WT_FAST);
         const int tilesX = cdiv(X, WTv), tilesY = cdiv(Y, WTv), ntiles = tilesX * tilesY;
         const int wtilesX = cdiv(X, WT_WIDE), wtilesY = cdiv(Y, WT_WIDE), wntiles = wtilesX * wtilesY;
         unsigned char *wchg = ws.get<unsigned char>((size_t)2 * wntiles);
@@ -1304,7 +1305,9 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
             case 10: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 128, 3, 6, 0, 1>), dim3(ntiles), dim3(128), lds_pad, WS_TILE_ARGS); break;
             case 11: TIP_LAUNCH("ws_tiles", (k_ws_tiles<32, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
             case 12: TIP_LAUNCH("ws_tiles", (k_ws_tiles<8, 64, 3, 6, 0, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
-            default: TIP_LAUNCH("ws_tiles", (k_ws_tiles<8, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 13: TIP_LAUNCH("ws_tiles", (k_ws_tiles<8, 64, 4, 6, 3, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            case 14: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 3, 6, 2, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
+            default: TIP_LAUNCH("ws_tiles", (k_ws_tiles<16, 64, 3, 6, 1, 1>), dim3(ntiles), dim3(64), lds_pad, WS_TILE_ARGS); break;
             }
 #undef WS_TILE_ARGS
             return TIP_OK;
