@@ -1080,8 +1080,20 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         unsigned cm = atoh_shift == 0 ? all : (pass == 0 ? (1u << ref_ch) : (all & ~(1u << ref_ch)));
         if (!cm) continue;
         if (fast && Zs <= 64 && !getenv("TIP_PROJECT_UNFUSED_MASK")) {
-            TIP_LAUNCH("mask_wmax_fused", (k_mask_wmax_fused<8>), dim3(cdiv(X, FT_X), cdiv(Y, FT_Y)), dim3(256),
-                       (size_t)Zs * Zs * sizeof(float), (const float *)table, sel, czyx, C, Z, zlo, Zs, Y, X, airyscan, cm, k2, proj);
+            // (instantiated per channel count: the per-channel running maxima are registers, 8 channels' worth of them cost
+            //  the two-channel case a third of its occupancy)
+            const dim3 fgrid(cdiv(X, FT_X), cdiv(Y, FT_Y));
+            const size_t flds = (size_t)Zs * Zs * sizeof(float);
+            if (C <= 2) {
+                TIP_LAUNCH("mask_wmax_fused", (k_mask_wmax_fused<2>), fgrid, dim3(256), flds, (const float *)table, sel, czyx, C, Z, zlo, Zs,
+                           Y, X, airyscan, cm, k2, proj);
+            } else if (C <= 4) {
+                TIP_LAUNCH("mask_wmax_fused", (k_mask_wmax_fused<4>), fgrid, dim3(256), flds, (const float *)table, sel, czyx, C, Z, zlo, Zs,
+                           Y, X, airyscan, cm, k2, proj);
+            } else {
+                TIP_LAUNCH("mask_wmax_fused", (k_mask_wmax_fused<8>), fgrid, dim3(256), flds, (const float *)table, sel, czyx, C, Z, zlo, Zs,
+                           Y, X, airyscan, cm, k2, proj);
+            }
         } else if (fast && Zs <= 64 && (long)Zs * Y < 2147483647L) {
             TIP_LAUNCH("mask_y_sparse", (k_mask_y_sparse<2>), dim3(cdiv(X, 256), cdiv(Y, 2 * MASK_W)), dim3(256),
                        (size_t)Zs * Zs * sizeof(float), (const float *)table, sel, Zs, Y, X, k2, A, zrange);
