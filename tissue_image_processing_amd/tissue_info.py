@@ -158,6 +158,75 @@ class TissueHipMixin(object):
         cells_info["n_neighbors"] = n_neighbors
         return
 
+    # ---- C4's caller: a drawn segmentation line splits a cell (ti.py:2878-2965) ------------------------------------
+    def get_new_labels(self, frame, n_new_labels):
+        """ti.py:2878-2897: label numbers for n new cells -- rows of deleted cells (empty_cell == 1) first, then fresh rows
+        after the table's end (after the label maximum when there is no table)."""
+        labels = self.get_labels(frame)
+        if labels is None:
+            return 0
+        table = self.get_cells_info(frame)
+        if table is None:
+            return np.max(labels) + np.arange(1, n_new_labels + 1)
+        free = table.index[table.empty_cell.to_numpy() == 1].to_numpy() + 1
+        if free.size >= n_new_labels and free.size > 0:
+            return free[:n_new_labels] if free.size > n_new_labels else free
+        return np.hstack((free, table.shape[0] + np.arange(1, n_new_labels - free.size + 1))).astype(np.int64)
+
+    def update_after_adding_segmentation_line(self, cell_label, frame):
+        """ti.py:2900-2965: after the user has drawn a line of zeros through cell `cell_label`, re-label the connected pieces
+        of the cell inside its bounding box (+2): the first piece keeps the label, the others get new ones; their table
+        rows (regionprops of the box), neighbour sets and type map follow.  Connected components and per-piece reductions
+        run on the device (label / regionprops on the box)."""
+        labels = self.get_labels(frame)
+        if labels is None:
+            return None
+        table = self.get_cells_info(frame)
+        cell_types = self.get_cell_types(frame)
+        if table is None:
+            where = np.argwhere(labels == cell_label)
+            r0, c0 = where.min(axis=0)
+            r1, c1 = where.max(axis=0) + 1
+        else:
+            row = table.iloc[cell_label - 1]
+            r0, c0, r1, c1 = (int(row["bounding_box_" + k]) for k in ("min_row", "min_col", "max_row", "max_col"))
+        fr, fc = max(0, int(r0) - 2), max(0, int(c0) - 2)
+        box = labels[fr:int(r1) + 2, fc:int(c1) + 2]                        # (a view: edits land in the frame's label map)
+        pieces = seg.label((box != 0).astype(int), connectivity=1, background=0)
+        piece_ids = np.unique(pieces[box == cell_label])
+        if piece_ids.size == 1:
+            print("New line did not split the cell")
+            return 0
+        new_labels = np.hstack((np.array([cell_label]), self.get_new_labels(frame, piece_ids.size - 1)))
+        for piece, lab in zip(piece_ids, new_labels):
+            box[pieces == piece] = lab
+        if table is None:
+            return None
+        try:
+            rp = seg.regionprops_arrays(np.ascontiguousarray(box))
+            areas = table.area.to_numpy()
+            smallest, largest = self.min_cell_area * np.mean(areas), self.max_cell_area * np.mean(areas)
+            old_neighbors = list(table.neighbors[cell_label - 1].copy())
+            old_type = table.type[cell_label - 1]
+            for lab in sorted(int(v) for v in new_labels):
+                if lab > rp["area"].size or rp["area"][lab - 1] == 0:
+                    continue
+                k = lab - 1
+                table.loc[k] = pd.Series({
+                    "area": rp["area"][k], "label": lab, "perimeter": rp["perimeter"][k],
+                    "cx": rp["cx"][k] + fc, "cy": rp["cy"][k] + fr,
+                    "bounding_box_min_row": rp["bbox"][k, 0] + fr, "bounding_box_min_col": rp["bbox"][k, 1] + fc,
+                    "bounding_box_max_row": rp["bbox"][k, 2] + fr, "bounding_box_max_col": rp["bbox"][k, 3] + fc,
+                    "valid": int(smallest < rp["area"][k] < largest), "empty_cell": 0, "neighbors": set(), "n_neighbors": 0,
+                    "type": int(old_type)})
+            self.find_neighbors(frame, only_for_labels=old_neighbors + list(new_labels))
+            if cell_types is not None:
+                for lab in new_labels:
+                    cell_types[labels == lab] = old_type if table.valid[lab - 1] else INVALID_TYPE_INDEX
+            return 0
+        except IndexError:
+            return 0
+
     # ---- C3 -------------------------------------------------------------------------------------------------
     def update_labels(self, frame):
         labels = self.get_labels(frame)

@@ -832,6 +832,57 @@ def gold_local_drifts():
     save("local_drifts", **out)
 
 
+def gold_split_cell():
+    """update_after_adding_segmentation_line / get_new_labels (ti.py:2878-2965): a drawn line (pixels set to 0) that splits a
+    cell in two / in three / not at all; re-use of an empty table row for the new cell; the no-table branch."""
+    g = np.load(os.path.join(OUT, "cellinfo.npz"))
+    base = g["a_labels"]
+    tmp = tempfile.mkdtemp(prefix="tipgold_")
+    out = {"base": base}
+
+    def run(tag, cell, lines, empty_row=None, with_table=True, with_types=True):
+        t = ti.Tissue(1, os.path.join(tmp, "movie_" + tag), ["zo"])
+        lab = base.copy()
+        t.set_labels(1, lab, reset_data=True)
+        if with_table:
+            t.calculate_frame_cellinfo(1)
+            if empty_row is not None:                      # a row of a deleted cell: its index is handed out again
+                ci = t.get_cells_info(1)
+                lab[lab == empty_row + 1] = 0
+                ci.at[empty_row, "empty_cell"] = 1
+                ci.at[empty_row, "valid"] = 0
+        if with_types:
+            types = np.full(lab.shape, 3, dtype=np.uint8)
+            types[lab == 0] = ti.INVALID_TYPE_INDEX
+            t.set_cell_types(1, types)
+        ys, xs = np.nonzero(lab == cell)
+        cy, cx = int(ys.mean()), int(xs.mean())
+        for kind, off in lines:                            # a straight cut through the cell's bounding box
+            if kind == "h":
+                lab[cy + off, xs.min():xs.max() + 1][lab[cy + off, xs.min():xs.max() + 1] == cell] = 0
+            else:
+                lab[ys.min():ys.max() + 1, cx + off][lab[ys.min():ys.max() + 1, cx + off] == cell] = 0
+        out[tag + "_in"] = lab.copy()
+        rc = t.update_after_adding_segmentation_line(cell, 1)
+        out[tag + "_rc"] = np.array(-1 if rc is None else rc)
+        out[tag + "_out"] = t.get_labels(1).copy()
+        if with_table:
+            for k, v in _cells_table(t, 1).items():
+                out[tag + "_" + k] = v
+        if with_types:
+            out[tag + "_types"] = t.get_cell_types(1).copy()
+        out[tag + "_cell"] = np.array(cell)
+
+    areas = np.bincount(base.ravel())[1:]
+    big = int(np.argmax(areas)) + 1
+    run("two", big, [("h", 0)])
+    run("three", big, [("h", -3), ("v", 2)])
+    run("none", big, [])
+    run("reuse", big, [("v", 0)], empty_row=4)
+    run("bare", big, [("h", 1)], with_table=False, with_types=False)
+    save("split_cell", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gold_weights()
@@ -853,4 +904,5 @@ if __name__ == "__main__":
     gold_seg()
     gold_manifold()
     gold_local_drifts()
+    gold_split_cell()
     print("done")
