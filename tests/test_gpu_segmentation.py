@@ -360,3 +360,23 @@ def test_tracking_golden(env, golden):
     tl = t.get_trackking_labels(3)
     lut = np.insert(g["ids_2"], 0, 0)
     np.testing.assert_array_equal(tl, lut[labs[2]])
+
+
+def test_calculate_mean_intensity(env, golden):
+    """ti.py:1135-1150 (regionprops 'intensity_mean' per cell, cached in the table): against numpy's per-label mean; the
+    property name upstream uses exists only in skimage >= 0.19, so there is no golden from the 0.18.3 environment."""
+    from tissue_image_processing_amd import tissue_info as ti
+    g = golden("celltypes")
+    lab, inten = g["labels"].copy(), g["intensity"]
+    lab[lab == 7] = 0                                   # a label that does not occur
+    t = ti.Tissue(1, "movie", ["zo", "atoh"])
+    t.set_labels(1, lab, reset_data=True)
+    t.calculate_frame_cellinfo(1)
+    valid = t.get_cells_info(1).query("valid == 1 and empty_cell == 0")
+    means = t.calculate_mean_intensity(1, valid, inten, "atoh")
+    want = np.array([inten[lab == i + 1].mean() for i in valid.index])
+    np.testing.assert_allclose(means, want, rtol=1e-12)
+    col = t.get_cells_info(1)["mean_intensity_atoh"].to_numpy()
+    assert np.isnan(col[6]) and not np.isnan(col[valid.index]).any()
+    again = t.calculate_mean_intensity(1, t.get_cells_info(1).query("valid == 1 and empty_cell == 0"), inten * 0, "atoh")
+    np.testing.assert_array_equal(again, means)          # cached column wins, as upstream

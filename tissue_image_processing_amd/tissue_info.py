@@ -239,6 +239,26 @@ class TissueHipMixin(object):
         self.update_cell_types_by_cells_info(frame)
         return 0
 
+    # ---- per-cell mean intensity (ti.py:1135-1150) ----------------------------------------------------------------------
+    def calculate_mean_intensity(self, frame, valid_cells, intensity_img, type_name):
+        """ti.py:1135-1150: mean of `intensity_img` over every cell (regionprops 'intensity_mean'), cached in the table's
+        `mean_intensity_<type_name>` column; returns the means of the rows of `valid_cells`.  One device pass over the frame
+        (tip_regionprops_i32 with an intensity plane); labels that do not occur have no mean upstream and none here."""
+        labels = self.get_labels(frame)
+        if labels is None:
+            return 0
+        column = "mean_intensity_" + type_name
+        if column in valid_cells.columns:
+            return valid_cells[column].to_numpy()
+        rp = seg.regionprops_arrays(labels, intensity=np.asarray(intensity_img))
+        present = np.flatnonzero(rp["area"] > 0)                    # regionprops_table lists the labels that occur
+        present_labels = present + 1
+        wanted = np.intersect1d(present_labels, valid_cells.index.to_numpy() + 1, return_indices=True)[1]
+        table = self.get_cells_info(frame)
+        if table is not None:
+            table.loc[present_labels - 1, column] = rp["intensity_mean"][present]
+        return rp["intensity_mean"][present][wanted]
+
     # ---- C5 -------------------------------------------------------------------------------------------------
     def calc_cell_types(self, type_marker_image, frame_number, type_name, threshold=0.1,
                         percentage_above_threshold=90, peak_window_size=0):
