@@ -380,3 +380,33 @@ def test_calculate_mean_intensity(env, golden):
     assert np.isnan(col[6]) and not np.isnan(col[valid.index]).any()
     again = t.calculate_mean_intensity(1, t.get_cells_info(1).query("valid == 1 and empty_cell == 0"), inten * 0, "atoh")
     np.testing.assert_array_equal(again, means)          # cached column wins, as upstream
+
+
+def test_whole_movie_refreshes(env, golden):
+    """update_bounding_box_for_all_cells / update_neighbors_for_all_cells (ti.py:4230-4247) restore what
+    calculate_frame_cellinfo wrote after the columns have been wiped."""
+    from tissue_image_processing_amd import tissue_info as ti
+    g = golden("cellinfo")
+    t = ti.Tissue(2, "movie", ["zo"])
+    for f, key in ((1, "a_labels"), (2, "b_labels")):
+        t.set_labels(f, g[key].copy(), reset_data=True)
+        t.calculate_frame_cellinfo(f)
+    before = [t.get_cells_info(f).copy(deep=True) for f in (1, 2)]
+    for f in (1, 2):
+        info = t.get_cells_info(f)
+        for edge in ("min_row", "min_col", "max_row", "max_col"):
+            info["bounding_box_" + edge] = -5
+        info["neighbors"] = [set() for _ in range(len(info))]
+        info["n_neighbors"] = 0
+    assert t.update_bounding_box_for_all_cells() == 0 and t.update_neighbors_for_all_cells() == 0
+    for f in (1, 2):
+        info = t.get_cells_info(f)
+        for edge in ("min_row", "min_col", "max_row", "max_col"):
+            present = before[f - 1]["area"].to_numpy() > 0
+            np.testing.assert_array_equal(info["bounding_box_" + edge].to_numpy()[present],
+                                          before[f - 1]["bounding_box_" + edge].to_numpy()[present])
+        valid = before[f - 1]["valid"].to_numpy() == 1
+        got = [sorted(s) for s in info.neighbors]
+        want = [sorted(s) for s in before[f - 1].neighbors]
+        # (find_neighbors without a label list covers every non-empty cell: a superset of what the valid-only pass recorded)
+        assert all(set(w) <= set(gv) for gv, w, v in zip(got, want, valid) if v)

@@ -239,6 +239,29 @@ class TissueHipMixin(object):
         self.update_cell_types_by_cells_info(frame)
         return 0
 
+    # ---- whole-movie refreshes (ti.py:4230-4247) ---------------------------------------------------------------------------
+    def update_bounding_box_for_all_cells(self):
+        """ti.py:4230-4241: bounding boxes of every frame's table from its label map (one device pass per frame)."""
+        for frame in range(1, self.number_of_frames + 1):
+            labels, table = self.get_labels(frame), self.get_cells_info(frame)
+            if table is None or labels is None:
+                continue
+            rp = seg.regionprops_arrays(labels)
+            rows = np.flatnonzero(rp["area"] > 0)
+            for j, edge in enumerate(("min_row", "min_col", "max_row", "max_col")):
+                table.loc[rows, "bounding_box_" + edge] = rp["bbox"][rows, j]
+            if hasattr(self, "save_cells_info"):
+                self.save_cells_info()
+        return 0
+
+    def update_neighbors_for_all_cells(self):
+        """ti.py:4243-4247."""
+        for frame in range(1, self.number_of_frames + 1):
+            self.find_neighbors(frame)
+            if hasattr(self, "save_cells_info"):
+                self.save_cells_info()
+        return 0
+
     # ---- per-cell mean intensity (ti.py:1135-1150) ----------------------------------------------------------------------
     def calculate_mean_intensity(self, frame, valid_cells, intensity_img, type_name):
         """ti.py:1135-1150: mean of `intensity_img` over every cell (regionprops 'intensity_mean'), cached in the table's
