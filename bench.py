@@ -460,9 +460,10 @@ def main():
         "unet": "surface_projection+unet_segmentation(%s,random-init,head bias calibrated to 50%% foreground)+threshold/closing/watershed tail+cell_tables"
                 % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}
 
-    # U-Net variant: two frames in flight -- the network saturates the chip on its own, but the tail's watershed has a
-    # sequential host stage (the heap-order recurrence of mode B) that the other frame's convolutions hide
-    unet_threads = max(1, min(2, args.inflight))
+    # U-Net variant: three frames in flight -- the network saturates the chip on its own, but the tail's watershed has a
+    # sequential host stage (the heap-order recurrence of mode B) and latency-bound generations that the other frames'
+    # convolutions hide (measured: 5.10 frames/s with two, 5.29 with three)
+    unet_threads = max(1, min(int(os.environ.get("TIP_BENCH_UNET_INFLIGHT", "3")), args.inflight))
     nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else min(unet_threads, args.steps)
     leg = run_leg(workload, nthreads, args.steps, args.warmup)
     unet_leg = None
