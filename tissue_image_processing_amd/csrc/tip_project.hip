@@ -583,8 +583,9 @@ static int launch_mfma2(const float *in, float *out, int Zs, int Y, int X, const
     const int r = t.n >> 1;
     if (r < 8 || r > 120 || r % MF_SEG) return fail(TIP_ERR_ARG, "mfma pass: radius %d (a multiple of %d in [8, 120])", r, MF_SEG);
     const int npos = MF_TO + 2 * r;
-    const int pitch = 514;                                // AXIS 2: 512 copied positions per line; 2 (mod 64): the 32 lines x 2
-                                                          // positions of an operand read hit 64 different banks
+    const int pitch = 513;                                // AXIS 2: 512 copied positions per line; odd: ds_read_b32 / ds_read2_b32 bank
+                                                          // on (address / 4) mod 32 within each 32-lane half, and a half holds the
+                                                          // 32 lines of one position (pitch 514 made lines l and l + 16 collide)
     const int bufsz = AXIS == 1 ? npos * MF_LN : MF_LN * pitch;
     const size_t lds = ((size_t)2 * bufsz + 2 * 127 + 64 + 64) * sizeof(float);   // + padded kernel + sink
     if (lds > 160 * 1024) return fail(TIP_ERR_ARG, "mfma pass: tile buffers exceed the LDS");
