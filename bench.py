@@ -468,7 +468,7 @@ def main():
     leg = run_leg(workload, nthreads, args.steps, args.warmup)
     unet_leg = None
     if workload == "classical" and not args.no_unet_leg and not args.include_upload:
-        unet_leg = run_leg("unet", min(unet_threads, max(1, args.unet_steps)), max(1, args.unet_steps), 2)
+        unet_leg = run_leg("unet", min(unet_threads, max(1, args.unet_steps)), max(1, args.unet_steps), max(2, unet_threads))
     del st, st_flip
 
     if rank == 0:
