@@ -175,13 +175,13 @@ def main():
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unet-leg", action="store_true", help="skip the secondary U-Net leg of the default run")
-    ap.add_argument("--unet-steps", type=int, default=6, help="timed steps of the secondary U-Net leg (2 warm-up steps)")
+    ap.add_argument("--unet-steps", type=int, default=9, help="timed steps of the secondary U-Net leg (2 warm-up steps)")
     ap.add_argument("--include-upload", action="store_true",
                     help="also time the host->device copy of every frame (pinned host buffers, copied by the worker that "
                          "then processes the frame, so uploads overlap other workers' kernels); NOT the headline value")
