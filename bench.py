@@ -364,12 +364,19 @@ def main():
 
         run_steps(max(warmup, nthreads))
         barrier()
-        all_workers(("prof", "on"))
-        barrier()
+        # The timed region runs the product path as a caller would: no per-kernel events (two hipEventRecord per launch cost
+        # the four-frame pipeline 3-5 % of its rate: 275 against 284 frames/s at 64 steps).  The same K steps are then repeated
+        # with the events on -- same threads, same frames in flight -- for `roofline_timed_region`.
         t0 = time.perf_counter()
         run_steps(steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        all_workers(("prof", "on"))
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(steps)
+        barrier()
+        elapsed_events = time.perf_counter() - t1
         all_workers(("prof", "off"))
         timed_reports = [dict(w.report) for w in workers]
         unet_ms = [m for w in workers for m in w.unet_ms]
@@ -386,7 +393,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return dict(elapsed=elapsed, timed=timed_reports, iso=iso_report, iso_steps=iso_steps, unet_ms=unet_ms,
+        return dict(elapsed=elapsed, elapsed_events=elapsed_events, timed=timed_reports, iso=iso_report, iso_steps=iso_steps, unet_ms=unet_ms,
                     iso_unet_ms=iso_unet_ms, nthreads=nthreads, steps=steps, warmup=warmup)
 
     def merge(reports):
@@ -478,6 +485,9 @@ def main():
                             "after the timed region (kernels of concurrent frames share the chip in the timed region)"
                             % leg["iso_steps"])
         roof_timed = roofline_of(merge(leg["timed"]), args.steps)
+        roof_timed["measured"] = ("HIP events on the library streams over a repeat of the timed region's %d steps with the same %d frames "
+                                  "in flight (%.1f frames/s with the events on; the timed region itself runs without them)"
+                                  % (args.steps, leg["nthreads"], world * args.steps / leg["elapsed_events"]))
         kernels = kernel_table(leg["iso"], leg["iso_steps"])
         # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are bound by the FP32 matrix pipe, not by HBM: the
         # banded-Toeplitz MFMA tiles issue 2 * (32 + 2 * 120) flop per voxel and pass (241 of the 272 products of an output
