@@ -126,3 +126,35 @@ def test_seg_archive_written_by_the_reference(tmp_path):
         np.testing.assert_array_equal(u.get_labels(f), t.get_labels(f))
         assert u.get_cells_info(f).equals(t.get_cells_info(f))
     np.testing.assert_array_equal(u.drifts, t.drifts)
+
+
+def test_remaining_bim_functions_golden(tmp_path):
+    """binary_image, read_part_of_image (with upstream's z-slice quirk), extract_all_frames_from_a_scene and
+    virtually_concatenate_time_points against the reference's own functions (tools/make_goldens.py gold_misc_io: tifffile's
+    BigTIFF writer real, the CZI reader an in-memory stand-in; the generator also checked that tifffile reads a BigTIFF
+    written here)."""
+    from tissue_image_processing_amd import basic_image_manipulations as bim
+    g = np.load(os.path.join(ROOT, "tests", "golden", "misc_io.npz"))
+    assert bool(g["tifffile_reads_mine"]) and bool(g["cat_is_bigtiff"])
+    np.testing.assert_array_equal(bim.binary_image(g["bin_cyx"], "CYX", 5.0), g["bin_cyx_scalar"])
+    np.testing.assert_array_equal(bim.binary_image(g["bin_cyx"], "CYX", [4.0, 6.0, 2.0]), g["bin_cyx_list"])
+    np.testing.assert_array_equal(bim.binary_image(g["bin_yxc"], "YXC", [3.0, 5.0, 7.0]), g["bin_yxc_list"])
+    np.testing.assert_array_equal(bim.binary_image(g["bin_yxc"], "YXC", 6.0), g["bin_yxc_scalar"])
+    np.testing.assert_array_equal(bim.binary_image(g["bin_tcyx"], "TCYX", (2.0, 8.0)), g["bin_tcyx_list"])
+    a, b = g["io_a"], g["io_b"]
+    scenes = [a, a[:, :, ::-1].copy()]
+    part, dims, _ = bim.read_part_of_image(scenes, (2, 9), (1, 8), (1, 4), (0, 2), (1, 3))
+    np.testing.assert_array_equal(part, g["part"])
+    part2, _, _ = bim.read_part_of_image(scenes, (2, 9), (1, 8), (0, 4), (0, 2), (0, 2), dims_order="CTZXY")
+    np.testing.assert_array_equal(part2, g["part2"])
+    assert (dims.T, dims.Z) == (3, 5)
+    frames = list(bim.extract_all_frames_from_a_scene(scenes, 1, max_frames=2))
+    np.testing.assert_array_equal(np.stack(frames), g["frames"])
+    whole, d2, _ = bim.read_whole_image(scenes)
+    np.testing.assert_array_equal(whole, a)
+    path = str(tmp_path / "cat.tif")
+    bim.virtually_concatenate_time_points([scenes, [b]], [2, 1], output_path=path)
+    raw = open(path, "rb").read(4)
+    assert raw[:2] == b"II" and raw[2] == 43               # BigTIFF
+    img, axes, shape, _ = bim.read_tiff(path)
+    np.testing.assert_array_equal(img, g["cat_pages"])

@@ -438,7 +438,7 @@ def _tiff_axes_from_description(desc, npages, rows, cols):
 
 def read_tiff(path):
     """bim.py:28-51: (image, axes, shape, metadata) of a TIFF file.  Self-contained reader for what this package and
-    ImageJ write -- classic (non-Big) TIFF, either byte order, uncompressed strips, one sample per pixel, 8 / 16 / 32-bit
+    ImageJ write -- classic TIFF and BigTIFF, either byte order, uncompressed strips, one sample per pixel, 8 / 16 / 32-bit
     unsigned, signed or float pages of one size; anything else raises."""
     import struct
     with open(path, "rb") as fh:
@@ -446,23 +446,32 @@ def read_tiff(path):
     if len(buf) < 8 or buf[:2] not in (b"II", b"MM"):
         raise ValueError("%s is not a TIFF file" % path)
     bo = "<" if buf[:2] == b"II" else ">"
-    magic, ifd = struct.unpack(bo + "HI", buf[2:8])
-    if magic != 42:
-        raise ValueError("%s: only classic TIFF is read here (magic %d)" % (path, magic))
-    sizes = {1: 1, 2: 1, 3: 2, 4: 4, 6: 1, 8: 2, 9: 4, 16: 8}
-    codes = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 16: "Q"}
+    magic, = struct.unpack(bo + "H", buf[2:4])
+    if magic == 42:                       # classic: 4-byte offsets, 12-byte entries, 2-byte entry count
+        big, ifd = False, struct.unpack(bo + "I", buf[4:8])[0]
+    elif magic == 43:                     # BigTIFF: 8-byte offsets, 20-byte entries, 8-byte entry count
+        big, ifd = True, struct.unpack(bo + "Q", buf[8:16])[0]
+    else:
+        raise ValueError("%s: not a TIFF / BigTIFF file (magic %d)" % (path, magic))
+    sizes = {1: 1, 2: 1, 3: 2, 4: 4, 6: 1, 8: 2, 9: 4, 16: 8, 17: 8}
+    codes = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 16: "Q", 17: "q"}
+    cnt_fmt, ent_size, inline, off_fmt = ("Q", 20, 8, "Q") if big else ("H", 12, 4, "I")
     pages, desc = [], ""
     while ifd:
-        n, = struct.unpack(bo + "H", buf[ifd:ifd + 2])
+        hdr = struct.calcsize(cnt_fmt)
+        n, = struct.unpack(bo + cnt_fmt, buf[ifd:ifd + hdr])
         tags = {}
         for k in range(n):
-            tag, typ, cnt, raw = struct.unpack(bo + "HHI4s", buf[ifd + 2 + 12 * k: ifd + 14 + 12 * k])
+            e = buf[ifd + hdr + ent_size * k: ifd + hdr + ent_size * (k + 1)]
+            tag, typ = struct.unpack(bo + "HH", e[:4])
+            cnt, = struct.unpack(bo + off_fmt, e[4:4 + inline])
+            raw = e[4 + inline:]
             if typ not in sizes:
                 continue
             nbytes = sizes[typ] * cnt
-            data = raw[:nbytes] if nbytes <= 4 else buf[struct.unpack(bo + "I", raw)[0]:][:nbytes]
+            data = raw[:nbytes] if nbytes <= inline else buf[struct.unpack(bo + off_fmt, raw)[0]:][:nbytes]
             tags[tag] = data if typ == 2 else struct.unpack(bo + "%d%s" % (cnt, codes[typ]), data)
-        ifd, = struct.unpack(bo + "I", buf[ifd + 2 + 12 * n: ifd + 6 + 12 * n])
+        ifd, = struct.unpack(bo + off_fmt, buf[ifd + hdr + ent_size * n: ifd + hdr + ent_size * n + inline])
         if tags.get(259, (1,))[0] != 1 or tags.get(277, (1,))[0] != 1:
             raise ValueError("%s: compressed or multi-sample pages are not read here" % path)
         cols, rows, bits = tags[256][0], tags[257][0], tags.get(258, (1,))[0]
@@ -504,3 +513,122 @@ def concatenate_time_points(files):
                                  % (img.shape[-2:], first.shape[-2:]))
         movies.append(img)
     return np.concatenate(movies, axis=0)
+
+
+# ---- the remaining small operators and readers of bim.py -------------------------------------------------------------------
+def binary_image(image, axes, thresholds):
+    """bim.py:350-369: per channel, values above the threshold become 1, then values below it become 0 -- two passes in that
+    order, so for a threshold above 1 the freshly written ones are zeroed again (as upstream) and values EQUAL to the
+    threshold keep their value; `thresholds` is a scalar or one value per channel (the first one when the image has no
+    channel axis, or the channel axis leads).  An elementwise pass over a display image: host numpy."""
+    adjusted = np.copy(image)
+    per_channel = hasattr(thresholds, "__len__")
+    if axes.find("C") > 0:
+        moved, order = put_channel_axis_first(adjusted, axes)
+        for channel in range(moved.shape[0]):
+            thr = thresholds[channel] if per_channel else thresholds
+            plane = moved[channel]
+            np.putmask(plane, plane > thr, 1)
+            np.putmask(plane, plane < thr, 0)
+        return np.transpose(moved, axes=np.argsort(order))
+    thr = thresholds[0] if per_channel else thresholds
+    np.putmask(adjusted, adjusted > thr, 1)
+    np.putmask(adjusted, adjusted < thr, 0)
+    return adjusted
+
+
+def _whole(src):
+    T, C, Z, Y, X = src.dims
+    return src.block(slice(0, T), slice(0, C), slice(0, Z), slice(0, Y), slice(0, X))
+
+
+def read_whole_image(path):
+    """bim.py:54-57: (data TCZYX, dims, metadata) of the first scene."""
+    src = open_image(path)
+    return _whole(src), src.dims, getattr(getattr(src, "img", None), "metadata", None)
+
+
+def read_virtual_image(path):
+    """bim.py:59-62: upstream returns the lazy (dask) array; here the source object itself plays that role: index it
+    through `.block(t, c, z, y, x)` slices, nothing is read before."""
+    src = open_image(path)
+    return src, src.dims, getattr(getattr(src, "img", None), "metadata", None)
+
+
+def read_part_of_image(path, x_range, y_range, z_range, c_range, t_range, dims_order="TCZXY"):
+    """bim.py:64-77: a sub-block of the first scene.  Kept as upstream wrote it: the z slice ends at c_range[1] (not
+    z_range[1]), and a `dims_order` other than the default transposes the TCZYX block by the index of each letter of
+    "TCZXY" in `dims_order`."""
+    src = open_image(path)
+    data = src.block(slice(t_range[0], t_range[1]), slice(c_range[0], c_range[1]), slice(z_range[0], c_range[1]),
+                     slice(y_range[0], y_range[1]), slice(x_range[0], x_range[1]))
+    default = "TCZXY"
+    if default != dims_order:
+        data = np.transpose(data, [dims_order.index(default[i]) for i in range(len(default))])
+    return data, src.dims, getattr(getattr(src, "img", None), "metadata", None)
+
+
+def extract_all_frames_from_a_scene(path, scene_index, max_frames=None):
+    """bim.py:497-509: generator over the time points of one scene, each as a (Z, C, Y, X) array (upstream asks its reader for
+    "TZCYX" order), at most `max_frames` of them."""
+    src = open_image(path, scene_index)
+    T, C, Z, Y, X = src.dims
+    for t in range(min(T, max_frames) if max_frames else T):
+        frame = src.block(slice(t, t + 1), slice(0, C), slice(0, Z), slice(0, Y), slice(0, X))[0]
+        yield np.transpose(frame, (1, 0, 2, 3))
+    return 0
+
+
+class _BigTiffAppender(object):
+    """Streaming BigTIFF writer (magic 43, 8-byte offsets): every (Y, X) plane appended becomes one page -- uncompressed,
+    min-is-black, one strip -- so a movie larger than memory (or than classic TIFF's 4 GiB) can be written frame by frame."""
+
+    def __init__(self, path):
+        import struct
+        self._s = struct
+        self.fh = open(path, "wb")
+        self.fh.write(struct.pack("<2sHHHQ", b"II", 43, 8, 0, 0))       # the first-IFD offset (bytes 8..15) is patched later
+        self.link = 8                                                  # file position of the pointer to the next IFD
+
+    def write_plane(self, plane):
+        s = self._s
+        plane = np.ascontiguousarray(plane)
+        if plane.ndim != 2 or plane.dtype not in (np.uint8, np.uint16, np.float32, np.int32):
+            raise TypeError("BigTIFF pages are 2-D uint8 / uint16 / int32 / float32 planes (got %s %s)" % (plane.dtype, plane.shape))
+        rows, cols = plane.shape
+        raw = plane.astype(plane.dtype.newbyteorder("<")).tobytes()
+        at = self.fh.seek(0, 2)
+        at += (-at) % 8
+        self.fh.seek(at)
+        self.fh.write(raw)
+        ifd = at + len(raw)
+        ifd += (-ifd) % 8
+        fmt = 3 if plane.dtype.kind == "f" else (2 if plane.dtype.kind == "i" else 1)
+        entries = [(256, 4, 1, cols), (257, 4, 1, rows), (258, 3, 1, plane.dtype.itemsize * 8), (259, 3, 1, 1), (262, 3, 1, 1),
+                   (273, 16, 1, at), (277, 3, 1, 1), (278, 4, 1, rows), (279, 16, 1, len(raw)), (339, 3, 1, fmt)]
+        self.fh.seek(ifd)
+        self.fh.write(s.pack("<Q", len(entries)))
+        for tag, typ, cnt, val in entries:
+            self.fh.write(s.pack("<HHQQ", tag, typ, cnt, val))
+        nxt = self.fh.tell()
+        self.fh.write(s.pack("<Q", 0))
+        self.fh.seek(self.link)
+        self.fh.write(s.pack("<Q", ifd))
+        self.link = nxt
+
+    def close(self):
+        self.fh.close()
+
+
+def virtually_concatenate_time_points(files, position_indices, output_path="output.tif"):
+    """bim.py:511-520: stream every time point of scene `position_indices[i] - 1` of `files[i]` into one BigTIFF, one
+    (Z, C, Y, X) frame at a time (upstream: tifffile.TiffWriter(bigtiff=True).write per frame): pages in frame, z, channel
+    order."""
+    out = _BigTiffAppender(output_path)
+    try:
+        for path, scene in zip(files, position_indices):
+            for frame in extract_all_frames_from_a_scene(path, scene - 1):
+                for plane in frame.reshape((-1,) + frame.shape[-2:]):
+                    out.write_plane(plane)
+    finally:
+        out.close()

@@ -556,6 +556,10 @@ class _Lazy(object):
     def __init__(self, a):
         self.a = a
 
+    @property
+    def shape(self):
+        return self.a.shape
+
     def __getitem__(self, k):
         return _Lazy(self.a[k])
 
@@ -583,8 +587,11 @@ class _FakeImage(object):
         t, c, z, y, x = self.scenes[self.scene].shape
         return _NS(T=t, C=c, Z=z, Y=y, X=x)
 
-    def get_image_dask_data(self):
-        return _Lazy(self.scenes[self.scene])
+    def get_image_dask_data(self, dimension_order_out=None):
+        a = self.scenes[self.scene]
+        if dimension_order_out:
+            a = np.transpose(a, ["TCZYX".index(ch) for ch in dimension_order_out])
+        return _Lazy(a)
 
     @property
     def metadata(self):
@@ -883,6 +890,45 @@ def gold_split_cell():
     save("split_cell", **out)
 
 
+def gold_misc_io():
+    """binary_image (bim.py:350-369), read_part_of_image (bim.py:64-77, with upstream's z-slice quirk), and the frame streamer
+    extract_all_frames_from_a_scene / virtually_concatenate_time_points (bim.py:497-520; tifffile's BigTIFF writer is real
+    here, only the CZI reader is the in-memory stand-in).  Also checks that tifffile reads a BigTIFF written by this package."""
+    import tifffile
+    from tissue_image_processing_amd import basic_image_manipulations as mine
+    bim.AICSImage = _FakeImage
+    bim.bioformats_reader = _NS(BioformatsReader=None)
+    rng = np.random.default_rng(700)
+    out = {}
+    img = np.round(rng.random((3, 9, 11)) * 10)                 # whole numbers: some pixels EQUAL a threshold
+    out.update(bin_cyx=img, bin_cyx_scalar=bim.binary_image(img, "CYX", 5.0), bin_cyx_list=bim.binary_image(img, "CYX", [4.0, 6.0, 2.0]))
+    yxc = np.round(rng.random((7, 8, 3)) * 10)
+    out.update(bin_yxc=yxc, bin_yxc_list=bim.binary_image(yxc, "YXC", [3.0, 5.0, 7.0]), bin_yxc_scalar=bim.binary_image(yxc, "YXC", 6.0))
+    tcyx = np.round(rng.random((2, 2, 5, 6)) * 10)
+    out.update(bin_tcyx=tcyx, bin_tcyx_list=bim.binary_image(tcyx, "TCYX", (2.0, 8.0)))
+    a = (rng.random((3, 2, 5, 12, 14)) * 60000).astype(np.uint16)
+    b = (rng.random((2, 2, 5, 12, 14)) * 60000).astype(np.uint16)
+    _FakeImage.registry["pa.czi"] = [a, a[:, :, ::-1].copy()]
+    _FakeImage.registry["pb.czi"] = [b]
+    part, _, _ = bim.read_part_of_image("pa.czi", (2, 9), (1, 8), (1, 4), (0, 2), (1, 3))
+    part2, _, _ = bim.read_part_of_image("pa.czi", (2, 9), (1, 8), (0, 4), (0, 2), (0, 2), dims_order="CTZXY")
+    out.update(io_a=a, io_b=b, part=part, part2=part2)
+    frames = list(bim.extract_all_frames_from_a_scene("pa.czi", 1, max_frames=2))
+    out.update(frames=np.stack(frames))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cat.tif")
+        bim.virtually_concatenate_time_points(["pa.czi", "pb.czi"], [2, 1], output_path=path)
+        with tifffile.TiffFile(path) as tf:
+            out.update(cat_pages=np.stack([p.asarray() for p in tf.pages]), cat_is_bigtiff=np.array(bool(tf.is_bigtiff)))
+        mpath = os.path.join(tmp, "mine.tif")
+        mine.virtually_concatenate_time_points([[a, a[:, :, ::-1].copy()], [b]], [2, 1], output_path=mpath)
+        with tifffile.TiffFile(mpath) as tf:
+            ok = bool(tf.is_bigtiff) and np.array_equal(np.stack([p.asarray() for p in tf.pages]), out["cat_pages"])
+        out["tifffile_reads_mine"] = np.array(ok)
+        assert ok
+    save("misc_io", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gold_weights()
@@ -905,4 +951,5 @@ if __name__ == "__main__":
     gold_manifold()
     gold_local_drifts()
     gold_split_cell()
+    gold_misc_io()
     print("done")
