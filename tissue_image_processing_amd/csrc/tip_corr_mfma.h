@@ -33,7 +33,9 @@ __global__ void __launch_bounds__(MF_NW * 64, 4) k_corr_long_mfma(const float *_
     const int r = taps.n >> 1;
     const int npos = MF_TO + 2 * r;
     const int pitch = AXIS == 1 ? MF_LN : npos + 1 + (npos & 1);      // AXIS 2: odd row pitch (lanes walk down the lines)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (fp32 MFMA shares the SIMD's vector ALUs on gfx950 -- see tip_corr_mfma2.h: wave index in a scalar register, packed
+    //  flush adds.  Scalar row bases for the 31 prefetch loads were tried: 119 spilled SGPRs, 0.72 ms instead of 0.67)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = AXIS == 1 ? Y : X;
     // zero-padded symmetric kernel: wfull[d + r + 31] = w(|d|) for |d| <= r, else 0
     for (int j = threadIdx.x; j < 2 * r + 63; j += MF_NW * 64) {
@@ -96,23 +98,31 @@ __global__ void __launch_bounds__(MF_NW * 64, 4) k_corr_long_mfma(const float *_
         fill();
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
-        f32x16 acc, tot;
+        f32x16 zero, tot;
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        f32x2_ tot2[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { acc[q] = 0.f; tot[q] = 0.f; }
+        for (int q = 0; q < 16; ++q) zero[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot2[q] = f32x2_{0.f, 0.f};
         const bool active = p0 + o0 < len;          // (wave-uniform: a whole 32-output group beyond the axis end does nothing)
         if (active) {
             // groups of MF_SEG K-steps (steps % MF_SEG == 0: checked by the launcher); the other waves of the SIMD cover
-            // the LDS latency of a group's operand reads (prefetching the next group in registers spills at 128 VGPRs)
+            // the LDS latency of a group's operand reads (prefetching the next group in registers spills at 128 VGPRs).
+            // A group's chain starts from a zero C operand and is flushed into the running total with packed adds.
             for (int s0 = 0; s0 < steps; s0 += MF_SEG) {
                 float a[MF_SEG], b[MF_SEG];
 #pragma unroll
                 for (int u = 0; u < MF_SEG; ++u) { a[u] = wp[2 * (s0 + u)]; b[u] = bp[(s0 + u) * bstep]; }
+                f32x16 acc = zero;
 #pragma unroll
                 for (int u = 0; u < MF_SEG; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { tot[q] += acc[q]; acc[q] = 0.f; }     // short partial sums: the certified bound
+                for (int q = 0; q < 8; ++q) tot2[q] += f32x2_{acc[2 * q], acc[2 * q + 1]};     // short partial sums: the certified bound
             }
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot[q] = tot2[q >> 1][q & 1];
         // D layout: lane l holds column j = l & 31, rows (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)
         if (AXIS == 1) {
             const int xx = l0 + i;
