@@ -362,8 +362,14 @@ def main():
             for w in workers:
                 w.wait()
 
+        def progress(msg):          # (stderr: a long U-Net leg must not look hung to whoever watches the run)
+            if rank == 0:
+                print("bench[%s]: %s" % (workload, msg), file=sys.stderr, flush=True)
+
+        progress("warm-up (%d frames in flight)" % nthreads)
         run_steps(max(warmup, nthreads))
         barrier()
+        progress("timed region: %d steps" % steps)
         # The timed region runs the product path as a caller would: no per-kernel events (two hipEventRecord per launch cost
         # the four-frame pipeline 3-5 % of its rate: 275 against 284 frames/s at 64 steps).  The same K steps are then repeated
         # with the events on -- same threads, same frames in flight -- for `roofline_timed_region`.
@@ -371,6 +377,7 @@ def main():
         run_steps(steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        progress("%.1f frames/s; the same steps again with per-kernel events" % (steps / elapsed))
         all_workers(("prof", "on"))
         barrier()
         t1 = time.perf_counter()
@@ -383,6 +390,7 @@ def main():
         # isolated pass: with several frames in flight kernels of different frames share the chip and every per-kernel
         # duration is inflated
         iso_steps = min(steps, 5)
+        progress("isolated pass: %d steps, one frame in flight" % iso_steps)
         workers[0].submit(("prof", "on")); workers[0].wait()
         run_steps(iso_steps, workers[:1])
         workers[0].submit(("prof", "off")); workers[0].wait()

@@ -58,14 +58,24 @@ def _normalize_sigma(std, ndim):
 def blur_image(image, std):
     """bim.py:373-390: scipy.ndimage.gaussian_filter(image, std, mode='nearest'); same shape and dtype out.
 
-    float32 / float64 arrays of rank 1..3 run on the GPU with scipy's exact arithmetic (double accumulation in
+    float32 / float64 arrays of any rank run on the GPU with scipy's exact arithmetic (double accumulation in
     scipy's tap order, rounding to the array dtype after each axis).  Integer images follow scipy's rule
     "output dtype == input dtype": they are filtered in float64 and truncated on store, as scipy's C core does.
     """
     image = np.asarray(image)
-    if image.ndim < 1 or image.ndim > 3:
-        raise ValueError("blur_image on MI355X supports rank 1..3 arrays (got rank %d)" % image.ndim)
+    if image.ndim < 1:
+        raise ValueError("blur_image needs an array of rank >= 1")
     sig = _normalize_sigma(std, image.ndim)
+    if image.ndim > 3:
+        # scipy filters axis after axis, rounding to the array dtype in between: for any rank that is one pass per axis over
+        # the (leading, axis, trailing) view of the array, each of them a rank-3 call below
+        cur = np.ascontiguousarray(image)
+        for ax in range(image.ndim):
+            if sig[ax] > 1e-15:
+                lead = int(np.prod(image.shape[:ax], dtype=np.int64))
+                trail = int(np.prod(image.shape[ax + 1:], dtype=np.int64))
+                cur = blur_image(cur.reshape(lead, image.shape[ax], trail), (0.0, sig[ax], 0.0)).reshape(image.shape)
+        return cur if cur is not image else image.copy()
     if np.issubdtype(image.dtype, np.integer) or image.dtype == bool:
         # scipy keeps the input dtype: every axis pass accumulates in double and the C core casts the result back to
         # the integer type (truncation toward zero) before the next axis sees it

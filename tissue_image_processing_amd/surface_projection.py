@@ -37,10 +37,16 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
         raise RuntimeError("sequence argument must have length equal to input rank")
     image = np.asarray(image)
     if image.dtype != np.uint16:
-        if np.issubdtype(image.dtype, np.integer) and image.size and image.min() >= 0 and image.max() <= 65535:
+        # upstream casts anything to float32 (sp.py:26); the device path reads uint16 voxels, so other dtypes are taken when
+        # they hold exactly such values (integer types in range, float stacks of whole numbers -- a uint16 movie that went
+        # through a float conversion), which float32 represents exactly: same arithmetic from there on
+        whole = image.size > 0 and (np.issubdtype(image.dtype, np.integer) or
+                                    (np.issubdtype(image.dtype, np.floating) and bool(np.all(np.floor(image) == image))))
+        if whole and image.min() >= 0 and image.max() <= 65535:
             image = image.astype(np.uint16)
         else:
-            raise TypeError("MI355X projection takes uint16 stacks (microscope data); got %s" % image.dtype)
+            raise TypeError("MI355X projection takes stacks of uint16 values (microscope data); got %s with fractional, "
+                            "negative or larger values" % image.dtype)
     image = np.ascontiguousarray(image)
     C, Z, Y, X = image.shape
     if not (-C <= reference_channel < C):

@@ -7,9 +7,14 @@ tag=${1:-r02x}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# heartbeat: a profiled run (MIOpen's solver search under the tracer) can be silent for minutes, and a silent command is
+# taken for a hung one
+( while true; do date +%T >> $out/heartbeat.txt; sleep 45; done ) &
+hb=$!
+trap "kill $hb 2>/dev/null" EXIT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s1 -o s1 -- python3 bench.py --inflight 1 --no-cpu-baseline --no-unet-leg > $out/${tag}_bench_inflight1_profiled.json 2> $out/s1.err || exit 1
 echo "stats inflight 1 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -o s3 -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_default_profiled.json 2> $out/s3.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -o s3 -- python3 bench.py --no-cpu-baseline --unet-steps 3 > $out/${tag}_bench_default_profiled.json 2> $out/s3.err || exit 1
 echo "stats default done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-unet-leg > $out/pf.json 2> $out/pf.err || exit 1
 echo "pmc fetch done"
