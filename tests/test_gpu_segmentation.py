@@ -217,6 +217,27 @@ def test_watershed_vs_oracle_synthetic_frame(env):
     assert mism == 0
 
 
+def test_watershed_tile_flavours_and_openings_agree(env, monkeypatch):
+    """The tile kernel's selectable flavours (TIP_WS_TILE: interior-only / evaluated margins, event-driven list or not, 8-,
+    16-, 32-pixel tiles) and openings (TIP_WS_OPEN) only change the schedule of certified decisions: every one of them gives
+    the oracle's labels."""
+    bim, _, _, orc = env
+    from tissue_image_processing_amd import synthetic, _segmentation as seg
+    from tissue_image_processing_amd import surface_projection as sp
+    st = synthetic.make_stack(8, 300, 340, seed=35)
+    proj = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False)
+    ref = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
+    for variant, opening in (("0", "10,8"), ("4", "6,6"), ("5", "8,6"), ("6", "6,6"), ("9", "3,2"), ("12", "12,9"), ("14", "1,1"),
+                             ("15", "8,6")):
+        monkeypatch.setenv("TIP_WS_TILE", variant)
+        monkeypatch.setenv("TIP_WS_OPEN", opening)
+        out = seg.watershed_segmentation(proj[0], 0.03, 3, 3)
+        assert int((out != ref).sum()) == 0, (variant, opening)
+    monkeypatch.delenv("TIP_WS_TILE"); monkeypatch.delenv("TIP_WS_OPEN")
+    monkeypatch.setenv("TIP_WS_NO_SKIP", "1")                 # stuck tiles re-run on every wake-up
+    assert int((seg.watershed_segmentation(proj[0], 0.03, 3, 3) != ref).sum()) == 0
+
+
 def test_headline_frame_segmentation_and_tables_bit_exact(env):
     """BASELINE's headline frame (2048x2048x30, C=2): the classical segmentation of the GPU projection and the cell
     tables on it, against the oracle's exact heap flood at FULL size (about 20 s of CPU)."""
