@@ -239,3 +239,26 @@ def test_display_ops_golden(env, golden, tmp_path):
         pages.append(np.frombuffer(raw[tags[273]:tags[273] + tags[279]], "<u2").reshape(tags[257], tags[256]))
         off = struct.unpack("<I", raw[off + 2 + 12 * n:off + 6 + 12 * n])[0]
     np.testing.assert_array_equal(np.stack(pages), g["st_u16"])
+
+
+def test_blur_image_radius_beyond_the_tap_table(env):
+    """sigma > 31.8 (more than 255 taps): the taps travel through device memory, same arithmetic -- equal to the oracle's
+    scipy restatement for float32 / float64 / uint16 arrays, along every axis."""
+    bim, _, _, orc = env
+    rng = np.random.default_rng(40)
+    for shape, sig in (((70, 90), 40.0), ((5, 60, 48), (0.0, 33.0, 45.5)), ((3, 300), (0.0, 100.0)), ((40, 6, 7), (50.0, 0.0, 0.0))):
+        for dt in (np.float32, np.float64, np.uint16):
+            a = (rng.random(shape) * 4000).astype(dt)
+            out = bim.blur_image(a, sig)
+            assert out.dtype == a.dtype
+            if dt == np.uint16:          # scipy keeps the integer dtype: float64 passes, truncated after every axis
+                ref = a.astype(np.float64)
+                sg = np.broadcast_to(np.asarray(sig, float), (a.ndim,))
+                for ax in range(a.ndim):
+                    one = np.zeros(a.ndim); one[ax] = sg[ax]
+                    if sg[ax] > 0:
+                        ref = np.trunc(orc.blur_image(ref, tuple(one)))
+                ref = ref.astype(np.uint16)
+            else:
+                ref = orc.blur_image(a, sig)
+            np.testing.assert_array_equal(out, ref, err_msg=str((shape, dt)))

@@ -101,9 +101,6 @@ def blur_image(image, std):
     for ax in range(src.ndim):
         if sig[ax] > 1e-15:
             taps[ax + 3 - src.ndim] = gaussian_taps(sig[ax])
-    for t in taps:
-        if t is not None and t.size > 255:
-            raise ValueError("blur_image on MI355X supports sigma <= 31.8 (radius <= 127)")
     out = np.empty_like(src)
     lib = _lib.lib()
     args = []

@@ -73,6 +73,24 @@ int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, i
     return fail(TIP_ERR_ARG, "correlate1d: dtype %d", dtype);
 }
 
+// taps in device memory (any odd, symmetric count): the generic kernel's arithmetic, for radii beyond the tap table
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256) k_corr_big(const T *__restrict__ in, T *__restrict__ out, int Z, int Y, int X,
+                                                  const double *__restrict__ w, int n)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= X) return;
+    const int r = n >> 1;
+    const int len = AXIS == 0 ? Z : (AXIS == 1 ? Y : X);
+    const int c = AXIS == 0 ? z : (AXIS == 1 ? y : x);
+    const long stride = AXIS == 0 ? (long)Y * X : (AXIS == 1 ? (long)X : 1L);
+    const T *line = in + ((long)z * Y + y) * X + x - (long)c * stride;      // element 0 of this output's line
+    auto at = [&](int i) -> double { return (double)line[(long)clampi(i, 0, len - 1) * stride]; };
+    double tmp = at(c) * w[r];
+    for (int d = r; d >= 1; --d) tmp += (at(c - d) + at(c + d)) * w[r - d];
+    out[((long)z * Y + y) * X + x] = (T)tmp;
+}
+
 // in -> out through up to three axis passes; `out` doubles as scratch together with one workspace.
 int gaussian3d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, const double *tz, int nz,
                    const double *ty, int ny, const double *tx, int nx)
@@ -98,13 +116,37 @@ int gaussian3d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, co
     int done = 0;
     for (int a = 0; a < 3; a++) {
         if (np_[a] <= 0) continue;
-        Taps t;
-        int rc = make_taps(t, tp[a], np_[a]);
-        if (rc) return rc;
         const int remaining = passes - done - 1;
         void *dst = (remaining % 2 == 0) ? out : tmp;
-        rc = correlate1d_dev(cur, dst, dtype, Z, Y, X, a, t, 0);
-        if (rc) return rc;
+        int rc;
+        if (np_[a] > 255) {
+            // radius > 127 (sigma > 31.8): more taps than the kernel-argument tap table holds; they go to device memory and a
+            // plain one-thread-per-output kernel walks them in scipy's order (no reference call site is this wide: slow path)
+            const int n = np_[a];
+            if (n % 2 == 0 || n > 8191) return fail(TIP_ERR_ARG, "gaussian: %d taps (odd, at most 8191)", n);
+            for (int i = 0; i < n / 2; ++i)
+                if (tp[a][i] != tp[a][n - 1 - i]) return fail(TIP_ERR_ARG, "gaussian: taps must be symmetric");
+            double *wd = ws.get<double>((size_t)n);
+            if (!wd) return TIP_ERR_NOMEM;
+            TIP_HIP(hipMemcpyAsync(wd, tp[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx().stream));
+            TIP_HIP(hipStreamSynchronize(ctx().stream));      // (the host tap array may be a temporary of the caller)
+            const dim3 grid(cdiv(X, 256), Y, Z);
+            if (dtype == 0) {
+                if (a == 0) { TIP_LAUNCH("corr_big", (k_corr_big<float, 0>), grid, dim3(256), 0, (const float *)cur, (float *)dst, Z, Y, X, (const double *)wd, n); }
+                else if (a == 1) { TIP_LAUNCH("corr_big", (k_corr_big<float, 1>), grid, dim3(256), 0, (const float *)cur, (float *)dst, Z, Y, X, (const double *)wd, n); }
+                else { TIP_LAUNCH("corr_big", (k_corr_big<float, 2>), grid, dim3(256), 0, (const float *)cur, (float *)dst, Z, Y, X, (const double *)wd, n); }
+            } else {
+                if (a == 0) { TIP_LAUNCH("corr_big", (k_corr_big<double, 0>), grid, dim3(256), 0, (const double *)cur, (double *)dst, Z, Y, X, (const double *)wd, n); }
+                else if (a == 1) { TIP_LAUNCH("corr_big", (k_corr_big<double, 1>), grid, dim3(256), 0, (const double *)cur, (double *)dst, Z, Y, X, (const double *)wd, n); }
+                else { TIP_LAUNCH("corr_big", (k_corr_big<double, 2>), grid, dim3(256), 0, (const double *)cur, (double *)dst, Z, Y, X, (const double *)wd, n); }
+            }
+        } else {
+            Taps t;
+            rc = make_taps(t, tp[a], np_[a]);
+            if (rc) return rc;
+            rc = correlate1d_dev(cur, dst, dtype, Z, Y, X, a, t, 0);
+            if (rc) return rc;
+        }
         cur = dst;
         done++;
     }
