@@ -175,7 +175,9 @@ def main():
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 64; 16 for --workload movie, whose every frame is a distinct synthetic stack "
+                         "generated on the host and kept in pinned memory)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
@@ -189,6 +191,8 @@ def main():
                     help="frames in flight per GPU: host threads, each with its own HIP stream and workspaces (the library "
                          "is re-entrant per thread, like the reference's Qt workers); frames are independent units")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 16 if args.workload == "movie" else 64
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
