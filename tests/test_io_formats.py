@@ -158,3 +158,31 @@ def test_remaining_bim_functions_golden(tmp_path):
     assert raw[:2] == b"II" and raw[2] == 43               # BigTIFF
     img, axes, shape, _ = bim.read_tiff(path)
     np.testing.assert_array_equal(img, g["cat_pages"])
+
+
+def test_local_drift_windows_and_sampling():
+    """Host parts of the local-drift map (ti.py:2149-2175): upstream's window enumeration (starts every step while
+    start < extent - window; a window that cannot be followed by a whole one runs to the edge) and the per-pixel mean of the
+    windows' shifts in loop order, against a literal dense restatement of upstream's accumulation."""
+    from tissue_image_processing_amd._registration import local_drift_windows, sample_local_drift
+    for (H, W), step, win in (((216, 216), 24, 64), ((2048, 2048), 100, 700), ((150, 90), 40, 60), ((64, 64), 10, 64), ((100, 300), 33, 50)):
+        wins = local_drift_windows((H, W), step, win)
+        exp = []
+        for r0 in range(0, H - win, step):
+            for c0 in range(0, W - win, step):
+                exp.append((r0, H if r0 + step + win > H else r0 + win, c0, W if c0 + step + win > W else c0 + win))
+        assert wins == exp
+        if (H, W) == (2048, 2048):
+            assert len(wins) == 196
+        rng = np.random.default_rng(H + W)
+        shifts = [(w, float(rng.normal()), float(rng.normal())) for w in wins]
+        sx, sy, cnt = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W))
+        for (r0, r1, c0, c1), dx, dy in shifts:                     # upstream's dense accumulation
+            sx[r0:r1, c0:c1] += dx; sy[r0:r1, c0:c1] += dy; cnt[r0:r1, c0:c1] += 1
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mx, my = sx / cnt, sy / cnt
+        rows, cols = rng.integers(0, H, 500), rng.integers(0, W, 500)
+        gx, gy = sample_local_drift(shifts, rows, cols)
+        np.testing.assert_array_equal(gx, mx[rows, cols])           # (NaN where no window covers the pixel, as upstream's 0 / 0)
+        np.testing.assert_array_equal(gy, my[rows, cols])
+    assert local_drift_windows((64, 64), 10, 64) == []              # frame not larger than the window: no windows at all
