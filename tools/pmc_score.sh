@@ -16,7 +16,16 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=Tru
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void tip::", "").replace("tip::", "")[:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
-for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CU_CYCLES", 0))[:6]:
-    a = acc[k]; calls = max(1, n[k].get("SQ_WAVE_CYCLES", 1))
-    print(k, {c: round(v / max(1, n[k][c]), 0) for c, v in sorted(a.items())})
+import json
+out = {}
+for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CU_CYCLES", 0))[:8]:
+    a = acc[k]
+    per = {c: round(v / max(1, n[k][c]), 0) for c, v in sorted(a.items())}      # per launch
+    busy = per.get("SQ_BUSY_CU_CYCLES", 0.0)
+    if busy:
+        per["mfma_pipe_busy_frac"] = round(per.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy / 4.0, 4)
+        per["lds_active_frac"] = round(per.get("SQ_LDS_IDX_ACTIVE", 0.0) / busy, 4)
+    out[k] = per
+    print(k, per)
+json.dump(out, open(sys.argv[1] + "/sq_projection.json", "w"), indent=1)
 PY
