@@ -305,30 +305,27 @@ class TissueHipMixin(object):
                                                       100 - percentage_above_threshold)[cell_indices]
         if new_type:
             cells_info.loc[cell_indices, "mean_intensity_" + type_name] = rp["intensity_mean"][cell_indices]
-        areas = cells_info.area.to_numpy()
-        mean_area = np.mean(areas)
-        max_area = self.max_cell_area * mean_area
-        min_area = self.min_cell_area * mean_area
-        old_valid = cells_info.valid.to_numpy() == 1
-        new_valid = np.logical_and(areas < max_area, areas > min_area)
-        updated_labels = cells_info.iloc[np.logical_and(new_valid, ~old_valid)].index.to_numpy() + 1
-        self.find_neighbors(frame_number, only_for_labels=updated_labels)
+        # validity follows the area rule of calculate_frame_cellinfo (ti.py:2360-2367); cells that become valid get neighbours
+        areas = cells_info["area"].to_numpy()
+        smallest, largest = self.min_cell_area * np.mean(areas), self.max_cell_area * np.mean(areas)
+        now_valid = np.logical_and(areas < largest, areas > smallest)
+        was_valid = cells_info["valid"].to_numpy() == 1
+        self.find_neighbors(frame_number, only_for_labels=cells_info.index[np.logical_and(now_valid, ~was_valid)].to_numpy() + 1)
         cells_info = self.get_cells_info(frame_number)
-        cells_info.loc[:, "valid"] = new_valid.astype(int)
-        max_brightness = seg.percentile_frame(img, 99)
-        thr = threshold * max_brightness
-        pos_indices = cell_indices[marker_intensities > thr]
-        neg_indices = cell_indices[marker_intensities <= thr]
+        cells_info.loc[:, "valid"] = now_valid.astype(int)
+        # a cell is positive when its percentile intensity exceeds `threshold` x the frame's 99th percentile (cells without
+        # pixels have NaN there and land in neither set, as upstream) -- and, with a peak window, holds a local maximum
+        cut = threshold * seg.percentile_frame(img, 99)
+        pos_indices = cell_indices[marker_intensities > cut]
+        neg_indices = cell_indices[marker_intensities <= cut]
         if peak_window_size > 0:
-            local_maxima = find_local_maxima(img, window_size=peak_window_size)
-            indices_with_local_maximum = np.unique(np.asarray(labels)[local_maxima]) - 1
-            indices_with_local_maximum = indices_with_local_maximum[indices_with_local_maximum > 0]
-            neg_indices = np.union1d(neg_indices, np.setdiff1d(pos_indices, indices_with_local_maximum))
-            pos_indices = np.intersect1d(pos_indices, indices_with_local_maximum)
-        current_type = cells_info.loc[pos_indices, "type"].to_numpy()
-        cells_info.loc[pos_indices, "type"] = change_type(current_type, type_index, is_positive=True)
-        current_type = cells_info.loc[neg_indices, "type"].to_numpy()
-        cells_info.loc[neg_indices, "type"] = change_type(current_type, type_index, is_positive=False)
+            peaks = find_local_maxima(img, window_size=peak_window_size)
+            with_peak = np.unique(np.asarray(labels)[peaks]) - 1
+            with_peak = with_peak[with_peak > 0]
+            neg_indices = np.union1d(neg_indices, np.setdiff1d(pos_indices, with_peak))
+            pos_indices = np.intersect1d(pos_indices, with_peak)
+        for rows, flag in ((pos_indices, True), (neg_indices, False)):
+            cells_info.loc[rows, "type"] = change_type(cells_info.loc[rows, "type"].to_numpy(), type_index, is_positive=flag)
         self.update_cell_types_by_cells_info(frame_number)
         return 0
 
