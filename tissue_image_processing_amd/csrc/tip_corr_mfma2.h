@@ -3,15 +3,16 @@
 // Same arithmetic (banded-Toeplitz float32 MFMA tiles, partial sums of 16 products), different pipeline: ONE persistent
 // block per CU owns two LDS tile buffers; while the eight waves run the MFMA loop on tile t they issue the loads of tile
 // t + gridDim.x as asynchronous global -> LDS copies (global_load_lds_dword: no register staging, no LDS-fill phase),
-// two copies per group of eight MFMAs, so that VMEM issue and address arithmetic hide under the matrix pipe.  One barrier
-// per tile.  (tip_corr_mfma.h's two register-staged blocks per CU run in lock-step -- both fill, then both compute -- and
-// leave the matrix pipe idle a third of the time.)
+// four copies per group of eight MFMAs in the first half of the tile (so that the last of them has half a tile to land).
+// One barrier per tile.  The float32 MFMA shares the SIMD's vector ALUs on gfx950 (see the kernel body), so the loop is
+// written for as few vector instructions as possible.
 //
 //   y pass (AXIS 1): LDS image [position][32 lines]; a copy instruction moves 2 positions x 32 lines (two 128-byte row
 //     segments); A = weights, B = samples, a lane's result column is a line -> 128-byte row segments to global memory.
 //   x pass (AXIS 2): LDS image [line][pitch] with an odd pitch: an operand read is served per 32-lane half (the 32 lines of
-//     one position) on 32 banks, so consecutive lines must land on consecutive banks; a copy instruction moves 64 consecutive positions of one line; A = samples,
-//     B = weights, so that a lane's result column is an output position -> rows are stored contiguously, no transposition.
+//     one position) on 32 banks, so consecutive lines must land on consecutive banks; a copy instruction moves 64
+//     consecutive positions of one line; A = samples, B = weights, so that a lane's result column is an output position ->
+//     rows are stored contiguously, no transposition.
 #pragma once
 #include "tip_corr_mfma.h"
 
