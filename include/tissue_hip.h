@@ -56,6 +56,16 @@ TIP_API int tip_memcpy_d2d(void *dst, const void *src, size_t bytes);   /* async
 TIP_API int tip_memcpy2d_d2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t height);
 TIP_API int tip_memset(void *dst, int value, size_t bytes);
 TIP_API int tip_sync(void);                       /* wait for this thread's stream */
+/* Tuning and test hooks, process-wide.  The library reads the TIP_* environment variables ONCE (at first use) and   */
+/* never again; afterwards a hook changes only through this call.  value NULL or "" restores the default.           */
+/*   TIP_WS_TIES = exact | fast          tie policy of the watershed (default exact, see below)                      */
+/*   TIP_WS_TILE, TIP_WS_OPEN = a,b, TIP_WS_CERT_FROM, TIP_WS_NO_SKIP, TIP_WS_LDS_PAD   tile flavour / schedule       */
+/*   TIP_WS_DEBUG, TIP_WS_NO_ENDGAME, TIP_WS_NO_WIDE                                   counters / stall machinery    */
+/*   TIP_PROJECT_EXACT_SCORE, TIP_PROJECT_GENERIC, TIP_PROJECT_UNFUSED_PREBLUR, TIP_PROJECT_UNFUSED_MASK,            */
+/*   TIP_PROJECT_DEBUG, TIP_FAST_CFG = y,x, TIP_MFMA_BLOCKS_PER_CU                     projection kernel selection   */
+/* None of them changes results: they select between schedules / kernels that are tested to agree bit for bit       */
+/* (TIP_WS_TIES = fast is the one exception and says so in `flags`).                                                */
+TIP_API int tip_set_tuning(const char *name, const char *value);
 
 /* per-kernel timing with HIP events on the library's own stream (bench.py roofline leg) */
 TIP_API int tip_prof_enable(int on);
@@ -125,6 +135,21 @@ TIP_API int tip_project_u16_hist_dev(const uint16_t *czyx, int c, int z, int y, 
 /* HIP's null stream, torch's default).  The convolutions themselves run in PyTorch-ROCm / MIOpen.                       */
 TIP_API int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const float *scale, const float *shift, long n, int c,
                                          void *stream);
+/* Ordering edges between the calling thread's library stream and another HIP stream (torch's current stream); neither */
+/* blocks the host.  tip_wait_stream: later library work starts after everything queued on `stream` so far -- call it  */
+/* AFTER allocating every torch tensor the library is going to write (the caching allocator hands out blocks whose     */
+/* previous owner's kernels may still be queued on that stream).  tip_stream_wait_tip: the other direction.            */
+/* >= 0: the device ordinal THIS library's HIP runtime attributes to device pointer p; negative: unknown to it (a     */
+/* second copy of libamdhip64 in the process) -- callers that pass torch pointers / streams check this once.          */
+TIP_API int tip_pointer_device(const void *p);
+TIP_API int tip_wait_stream(void *stream);
+TIP_API int tip_stream_wait_tip(void *stream);
+/* pl.py:167-194 after the network, one submission: p = class-0 probability map on the device (y rows of x values, row  */
+/* pitch ld elements; dtype 0 = float32, 1 = float64) -> 255 (p > thr) -> 5x5 closing -> HC = 7x7 erosion -> boundary = */
+/* 5x5 dilation of (closed - HC) -> watershed(watershed_line=True).  labels / hc: caller-owned device buffers (y * x).  */
+/* A boundary image that is not two-valued is an error (corrupted intermediate), never a slow flood.                   */
+TIP_API int tip_unet_tail_dev(const void *p, int dtype, long ld, int y, int x, double thr, int32_t *labels, double *hc,
+                              int32_t *flags_host);
 
 /* ---- rank filters ---------------------------------------------------------------------------- */
 /* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */
@@ -145,16 +170,31 @@ TIP_API int tip_label4_i32(const int32_t *in, int32_t bg, int32_t *out, int y, i
 TIP_API int tip_label4_i32_dev(const int32_t *in, int32_t bg, int32_t *out, int y, int x, int32_t *n_labels_host);
 
 /* ---- watershed: skimage.segmentation.watershed(markers=None, connectivity=1) (bim.py:475, pl.py:194) */
-/* markers = label(local_minima(img)).  flags (out, may be NULL): bit0 = value ties between        */
-/* non-marker neighbours were met; bit1 = the image is two-valued (pl.py:194) and was flooded by    */
-/* the generation-ranked mode, which reproduces the serial (value, age) heap order exactly, so bit0 */
-/* only means "not bit for bit" when bit1 is clear; bits 2.. = global-minimum fallback steps.      */
+/* markers = label(local_minima(img)).  The result equals skimage's bit for bit.  Three routes, reported in `flags`  */
+/* (out, may be NULL):                                                                                               */
+/*   - landscapes whose non-marker pixels carry distinct values: the data-parallel certified flood (no flag);        */
+/*   - two-valued images (pl.py:194): TIP_WS_FLAG_TWO_VALUED, the generation-ranked flood, exact;                    */
+/*   - other landscapes with value ties (TIP_WS_FLAG_TIES; the uint16 frames of gui.py:1841-1845): skimage's result */
+/*     is a function of its heap array's history, so the flood itself runs as the exact serial (value, age) replay  */
+/*     on one host core (TIP_WS_FLAG_SERIAL_EXACT; ~0.3 us per pixel), markers before and everything after on the   */
+/*     device.  tip_set_tuning("TIP_WS_TIES", "fast") keeps such images on the device instead: ties are then broken */
+/*     by raster index, not by push age, and the labels differ from skimage's in a fraction of the pixels.          */
+/* TIP_WS_FLAG_SERIAL_FINISH: the device flood stalled on a serial dependency chain (plateaus larger than any       */
+/* certificate; only with the fast tie policy) and the rest was finished on the host; the number of pixels decided  */
+/* there is flags >> TIP_WS_FLAG_COUNT_SHIFT (saturating at 2^23 - 1).                                              */
+#define TIP_WS_FLAG_TIES 1
+#define TIP_WS_FLAG_TWO_VALUED 2
+#define TIP_WS_FLAG_SERIAL_EXACT 4
+#define TIP_WS_FLAG_SERIAL_FINISH 8
+#define TIP_WS_FLAG_COUNT_SHIFT 8
 TIP_API int tip_watershed_f64(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags);
 TIP_API int tip_watershed_f64_dev(const double *img, int32_t *labels, int y, int x, int wsl, int32_t *flags_host);
 /* Pop order of m equal-keyed heap entries pushed in raster order when popping entry i is followed  */
 /* by c[i] pushes of larger entries (skimage's heap_general.pxi mechanics; the marker phase of      */
 /* pl.py:194): e[i] = position of entry i in the pop order.  Host arrays, no device involved.      */
 TIP_API int tip_marker_pop_order_host(const uint8_t *c, long m, uint32_t *e);
+/* The serial (value, age) flood by itself: host arrays, markers given (> 0 = seed), no device involved.            */
+TIP_API int tip_watershed_serial_host(const double *img, const int32_t *markers, int32_t *labels, int y, int x);
 /* number of labels (= markers) produced by the calling thread's last watershed call                 */
 TIP_API int tip_last_watershed_labels(void);
 /* bim.py:446-476 as one device pipeline: local threshold -> Gaussian(sigma) -> watershed          */

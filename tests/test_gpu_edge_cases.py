@@ -177,7 +177,7 @@ def test_integer_images_follow_scipy_truncation(env):
     np.testing.assert_array_equal(bim.blur_image(i16, (1, 2)), ndi.gaussian_filter(i16, (1, 2), mode="nearest"))
     labels, flags = seg.watershed_segmentation(img, 0.03, 3, 3, return_flags=True)
     assert labels.dtype == np.int32 and labels.max() > 10
-    assert flags & 1        # integer landscape: value ties between neighbours are reported
+    assert flags & 1 and flags & 4        # integer landscape: value ties are reported and flooded by the exact serial replay
 
 
 def test_cell_tables_with_more_labels_than_tile_slots():

@@ -47,16 +47,15 @@ def test_world2_equals_world1(tmp_path):
     assert np.all(np.abs(a["est"][1:] - np.array([-0.5, 0.3])) < 1.0)
 
 
-def test_watershed_fallback_paths_agree(monkeypatch):
-    from tissue_image_processing_amd import _segmentation as seg
+def test_watershed_fallback_paths_agree():
+    from tissue_image_processing_amd import _segmentation as seg, _lib
     rng = np.random.default_rng(4)
     img = rng.random((150, 170))          # white noise: many lines, many stuck pockets
     ref, f0 = seg.watershed(img, return_flags=True)
-    monkeypatch.setenv("TIP_WS_NO_ENDGAME", "1")
-    out, f1 = seg.watershed(img, return_flags=True)
-    monkeypatch.delenv("TIP_WS_NO_ENDGAME")
+    with _lib.tuning(TIP_WS_NO_ENDGAME="1"):
+        out, f1 = seg.watershed(img, return_flags=True)
     np.testing.assert_array_equal(out, ref)
-    print("fallback steps with the endgame disabled:", f1 >> 2)
+    print("pixels finished serially with the endgame disabled:", f1 >> _lib.WS_FLAG_COUNT_SHIFT)
 
 
 def _groove_image(K=14, H=24, W=41):
@@ -74,19 +73,20 @@ def _groove_image(K=14, H=24, W=41):
     return img
 
 
-def test_watershed_global_minimum_fallback(monkeypatch):
-    """With the endgame and the wide pass disabled a long stuck pocket is released by committing the pixel with the
-    globally smallest pop time, one at a time: slow, always terminates, same labels (and equal to the serial oracle)."""
+def test_watershed_serial_finish():
+    """With the endgame and the wide pass disabled a long stuck pocket is a serial dependency chain the tile rounds cannot
+    release: the rest of the flood is finished by the host stage (one pass, same pop-time rule) -- same labels, equal to the
+    serial oracle, and `flags` says so."""
     from oracle import oracle as orc
-    from tissue_image_processing_amd import _segmentation as seg
+    from tissue_image_processing_amd import _segmentation as seg, _lib
     img = _groove_image()
     ref = seg.watershed(img)
     np.testing.assert_array_equal(ref, orc.watershed(img))
-    monkeypatch.setenv("TIP_WS_NO_ENDGAME", "1")
-    out_w, flags_w = seg.watershed(img, return_flags=True)           # wide pass available
-    np.testing.assert_array_equal(out_w, ref)
-    monkeypatch.setenv("TIP_WS_NO_WIDE", "1")
-    out, flags = seg.watershed(img, return_flags=True)                # only the global-minimum commits are left
+    with _lib.tuning(TIP_WS_NO_ENDGAME="1"):
+        out_w, flags_w = seg.watershed(img, return_flags=True)           # wide pass available
+        np.testing.assert_array_equal(out_w, ref)
+        with _lib.tuning(TIP_WS_NO_WIDE="1"):
+            out, flags = seg.watershed(img, return_flags=True)            # only the serial finish is left
     np.testing.assert_array_equal(out, ref)
-    assert flags >> 2 > 0     # the fallback really ran
-    print("global-minimum fallback steps:", flags >> 2, "(wide pass needed", flags_w >> 2, ")")
+    assert flags & _lib.WS_FLAG_SERIAL_FINISH and flags >> _lib.WS_FLAG_COUNT_SHIFT > 0
+    print("pixels finished serially:", flags >> _lib.WS_FLAG_COUNT_SHIFT, "(with the wide pass:", flags_w >> _lib.WS_FLAG_COUNT_SHIFT, ")")

@@ -163,27 +163,13 @@ def test_watershed_binary_degenerate_shapes(env):
         assert mism == 0, "case %d: %d mismatches" % (k, mism)
 
 
-def test_watershed_value_ties_deviation_is_bounded(env, golden):
-    """KNOWN DEVIATION, measured here so that it cannot grow silently.  On landscapes whose NON-marker pixels tie in value
-    (integer images: the GUI's uint16 frames, gui.py:1841-1845; golden `v`, a landscape quantised to a few levels) skimage
-    orders equal values by heap push age and equal-keyed markers by the mechanics of its array heap; mode A orders ties by
-    raster index, so watershed lines on plateaus can sit a pixel off.  Markers, label count and the segmentation away from
-    plateaus are the same.  (Two-valued images -- mode B -- and tie-free landscapes are bit exact)"""
-    _, seg, _, orc = env
-    g = golden("watershed")
-    out, flags = seg.watershed(g["v_img"], return_flags=True)
-    ref = g["v_labels"]
-    assert flags & 1 and not (flags & 2)
-    assert out.max() == ref.max()
-    frac_v = float((out != ref).mean())
-    print("golden v (few-level landscape): mismatching pixels %.2f%%, IoU %.3f" % (100 * frac_v, label_iou(out, ref)))
-    assert frac_v < 0.40
-    # the classical path on a uint16-normalised frame (save_tiff's normalisation, bim.py:183-188)
+def _uint16_frame_and_reference(orc, N, seed=44):
+    """A uint16-normalised projection (save_tiff's normalisation, bim.py:183-188) and the oracle's restatement of what
+    bim.py:446-476 does to it: threshold, scipy's integer-dtype blur (truncation after every axis), serial flood."""
     from tissue_image_processing_amd import synthetic, surface_projection as sp
-    st = synthetic.make_stack(10, 512, 512, seed=44)
+    st = synthetic.make_stack(10, N, N, seed=seed)
     proj, _ = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
     img16 = np.round(proj[0] / proj[0].max() * 65535).astype(np.uint16)
-    lab, flags = seg.watershed_segmentation(img16, 0.03, 3, 3, return_flags=True)
     s16 = img16.copy()
     thr = orc.threshold_local_generic_max(s16.astype(np.float64), 0.03, 3)
     s16[s16 < thr] = 0
@@ -191,14 +177,94 @@ def test_watershed_value_ties_deviation_is_bounded(env, golden):
     for ax in range(2):
         sg = [0, 0]
         sg[ax] = 3
-        cur = np.trunc(orc.blur_image(cur, tuple(sg)))          # scipy keeps uint16: truncation after every axis
-    ref16 = orc.watershed(cur)
-    frac = float((lab != ref16).mean())
-    iou = label_iou(lab, ref16)
-    print("uint16 512^2 frame: %d labels (ref %d), mismatching pixels %.3f%%, IoU %.4f" % (lab.max(), ref16.max(), 100 * frac, iou))
-    assert flags & 1
-    assert lab.max() == ref16.max()
-    assert frac < 0.02 and iou > 0.97
+        cur = np.trunc(orc.blur_image(cur, tuple(sg)))
+    return img16, orc.watershed(cur)
+
+
+def test_watershed_value_ties_are_exact(env, golden):
+    """Landscapes whose non-marker pixels tie in value (integer images: the GUI's uint16 frames, gui.py:1841-1845; golden `v`,
+    a landscape quantised to a few levels): skimage orders equal values by heap push age and equal-keyed markers by the
+    mechanics of its array heap.  The default tie policy reproduces that bit for bit (markers on the device, the flood
+    itself as the serial replay of csrc/tip_ws_serial.hip): golden `v` from the reference, and the classical path on a
+    512^2 uint16 frame against the oracle."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    g = golden("watershed")
+    out, flags = seg.watershed(g["v_img"], return_flags=True)
+    assert flags & _lib.WS_FLAG_TIES and flags & _lib.WS_FLAG_SERIAL_EXACT and not (flags & _lib.WS_FLAG_TWO_VALUED)
+    np.testing.assert_array_equal(out, g["v_labels"])
+    img16, ref16 = _uint16_frame_and_reference(orc, 512)
+    lab, flags = seg.watershed_segmentation(img16, 0.03, 3, 3, return_flags=True)
+    assert flags & _lib.WS_FLAG_SERIAL_EXACT
+    np.testing.assert_array_equal(lab, ref16)
+
+
+def test_watershed_value_ties_exact_at_2048(env):
+    """The same at the headline frame size: a 2048^2 uint16-normalised frame through watershed_segmentation, 0 mismatches
+    against the oracle's serial flood."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    import time
+    img16, ref16 = _uint16_frame_and_reference(orc, 2048, seed=45)
+    t0 = time.perf_counter()
+    lab, flags = seg.watershed_segmentation(img16, 0.03, 3, 3, return_flags=True)
+    dt = time.perf_counter() - t0
+    mism = int((lab != ref16).sum())
+    print("uint16 2048^2 frame: %d labels, exact tie policy %.2f s, mismatches %d" % (ref16.max(), dt, mism))
+    assert flags & _lib.WS_FLAG_SERIAL_EXACT
+    assert mism == 0
+
+
+def test_watershed_fast_tie_policy_deviation_is_bounded(env, golden):
+    """tip_set_tuning("TIP_WS_TIES", "fast") keeps tie landscapes on the device: mode A breaks ties by raster index instead of
+    push age, so watershed lines on plateaus can sit a pixel off (same markers, same label count).  The deviation is
+    measured here so that it cannot grow silently; the default policy (above) has none."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    g = golden("watershed")
+    with _lib.tuning(TIP_WS_TIES="fast"):
+        out, flags = seg.watershed(g["v_img"], return_flags=True)
+        ref = g["v_labels"]
+        assert flags & _lib.WS_FLAG_TIES and not (flags & (_lib.WS_FLAG_TWO_VALUED | _lib.WS_FLAG_SERIAL_EXACT))
+        assert out.max() == ref.max()
+        frac_v = float((out != ref).mean())
+        print("fast policy, golden v (few-level landscape): mismatching pixels %.2f%%, IoU %.3f" % (100 * frac_v, label_iou(out, ref)))
+        assert frac_v < 0.40
+        img16, ref16 = _uint16_frame_and_reference(orc, 512)
+        lab, flags = seg.watershed_segmentation(img16, 0.03, 3, 3, return_flags=True)
+        frac = float((lab != ref16).mean())
+        iou = label_iou(lab, ref16)
+        print("fast policy, uint16 512^2 frame: %d labels (ref %d), mismatching pixels %.3f%%, IoU %.4f, serial finish %d px" % (
+            lab.max(), ref16.max(), 100 * frac, iou, flags >> _lib.WS_FLAG_COUNT_SHIFT))
+        assert flags & _lib.WS_FLAG_TIES and not (flags & _lib.WS_FLAG_SERIAL_EXACT)
+        assert lab.max() == ref16.max()
+        assert frac < 0.02 and iou > 0.97
+
+
+def test_watershed_large_plateau_does_not_crawl(env):
+    """A noisy integer image with large equal-valued plateaus under the FAST policy: mode A's certificates cannot close
+    plateau-sized pockets, and the rest used to be committed one pixel per host round trip (minutes).  Now the stalled rest
+    is finished in one serial pass on the host: seconds, and equal to a serial flood with the same (value, raster index)
+    order."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    import time
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 3, (600, 700)).astype(np.float64)
+    img[100:400, 150:600] = 1.0                     # a 135 000-pixel plateau
+    with _lib.tuning(TIP_WS_TIES="fast"):
+        t0 = time.perf_counter()
+        out, flags = seg.watershed(img, return_flags=True)
+        dt = time.perf_counter() - t0
+    print("large plateau, fast policy: %.2f s, flags %#x, serial finish %d px" % (dt, flags & 0xff, flags >> _lib.WS_FLAG_COUNT_SHIFT))
+    assert dt < 20.0
+    # raster-index tie order == the serial flood of an image whose ties are broken by a tiny raster-increasing ramp
+    ramp = img + np.arange(img.size).reshape(img.shape) * 1e-9
+    mk = orc.label4(orc.local_minima(img).astype(np.int32), 0)[0]
+    np.testing.assert_array_equal(out, orc.watershed(ramp, markers=mk))
+    out_exact, fl = seg.watershed(img, return_flags=True)
+    assert fl & _lib.WS_FLAG_SERIAL_EXACT
+    np.testing.assert_array_equal(out_exact, orc.watershed(img))
 
 
 def test_watershed_vs_oracle_synthetic_frame(env):
@@ -213,29 +279,28 @@ def test_watershed_vs_oracle_synthetic_frame(env):
         zo, 0.03, 3, 3, return_flags=True)
     ref = orc.watershed_segmentation(zo, 0.03, 3, 3)
     mism = int((out != ref).sum())
-    print("synthetic frame: %d labels, flags %d (fallback steps %d), mismatches %d" % (ref.max(), flags & 3, flags >> 2, mism))
+    print("synthetic frame: %d labels, flags %#x, mismatches %d" % (ref.max(), flags, mism))
+    assert flags == 0          # tie-free float landscape: the data-parallel flood, no serial stage
     assert mism == 0
 
 
-def test_watershed_tile_flavours_and_openings_agree(env, monkeypatch):
+def test_watershed_tile_flavours_and_openings_agree(env):
     """The tile kernel's selectable flavours (TIP_WS_TILE: interior-only / evaluated margins, event-driven list or not, 8-,
     16-, 32-pixel tiles) and openings (TIP_WS_OPEN) only change the schedule of certified decisions: every one of them gives
     the oracle's labels."""
     bim, _, _, orc = env
-    from tissue_image_processing_amd import synthetic, _segmentation as seg
+    from tissue_image_processing_amd import synthetic, _segmentation as seg, _lib
     from tissue_image_processing_amd import surface_projection as sp
     st = synthetic.make_stack(8, 300, 340, seed=35)
     proj = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False)
     ref = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
     for variant, opening in (("0", "10,8"), ("4", "6,6"), ("5", "8,6"), ("6", "6,6"), ("9", "3,2"), ("12", "12,9"), ("14", "1,1"),
                              ("15", "8,6")):
-        monkeypatch.setenv("TIP_WS_TILE", variant)
-        monkeypatch.setenv("TIP_WS_OPEN", opening)
-        out = seg.watershed_segmentation(proj[0], 0.03, 3, 3)
+        with _lib.tuning(TIP_WS_TILE=variant, TIP_WS_OPEN=opening):
+            out = seg.watershed_segmentation(proj[0], 0.03, 3, 3)
         assert int((out != ref).sum()) == 0, (variant, opening)
-    monkeypatch.delenv("TIP_WS_TILE"); monkeypatch.delenv("TIP_WS_OPEN")
-    monkeypatch.setenv("TIP_WS_NO_SKIP", "1")                 # stuck tiles re-run on every wake-up
-    assert int((seg.watershed_segmentation(proj[0], 0.03, 3, 3) != ref).sum()) == 0
+    with _lib.tuning(TIP_WS_NO_SKIP="1"):                     # stuck tiles re-run on every wake-up
+        assert int((seg.watershed_segmentation(proj[0], 0.03, 3, 3) != ref).sum()) == 0
 
 
 def test_headline_frame_segmentation_and_tables_bit_exact(env):
@@ -251,7 +316,8 @@ def test_headline_frame_segmentation_and_tables_bit_exact(env):
     ref = orc.watershed_segmentation(zo, 0.03, 3, 3)
     assert int(ref.max()) > 4000
     mism = int((out != ref).sum())
-    print("headline frame: %d labels, flags %d (fallback steps %d), mismatches %d" % (ref.max(), flags & 3, flags >> 2, mism))
+    print("headline frame: %d labels, flags %#x, mismatches %d" % (ref.max(), flags, mism))
+    assert flags == 0          # tie-free float landscape: the data-parallel flood, no serial stage
     assert mism == 0
     got = seg.regionprops_arrays(out)
     want = orc.regionprops(ref)

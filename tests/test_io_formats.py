@@ -186,3 +186,54 @@ def test_local_drift_windows_and_sampling():
         np.testing.assert_array_equal(gx, mx[rows, cols])           # (NaN where no window covers the pixel, as upstream's 0 / 0)
         np.testing.assert_array_equal(gy, my[rows, cols])
     assert local_drift_windows((64, 64), 10, 64) == []              # frame not larger than the window: no windows at all
+
+
+def test_legacy_single_type_archive_is_upgraded_like_upstream(tmp_path):
+    """Old archives hold a 0 / 1 / 2 type map (0 invalid, 1 HC, 2 SC) and a str-typed `type` column.  Upstream's upgrade
+    (ti.py:4211-4228): table "HC" -> 1, "SC" / "invalid" -> 0; map 0 -> INVALID (255) and then 2 -> 0, in that order, so an
+    SC pixel reads as negative for every type."""
+    import io
+    import zipfile
+    import pandas as pd
+    from tissue_image_processing_amd import tissue_info as ti
+    types = np.array([[0, 1, 2], [2, 2, 1], [0, 0, 1]], np.uint8)
+    labels = np.arange(1, 10, dtype=np.int32).reshape(3, 3)
+    info = pd.DataFrame({"label": [1, 2, 3], "type": ["HC", "SC", "invalid"], "valid": [1, 1, 0]})
+    path = str(tmp_path / "old.seg")
+    with zipfile.ZipFile(path, "w") as z:
+        for name, arr in (("frame_1_labels.npy", labels), ("frame_1_types.npy", types)):
+            fh = io.BytesIO()
+            np.save(fh, arr)
+            z.writestr(name, fh.getvalue())
+        fh = io.BytesIO()
+        info.to_pickle(fh, compression=None)
+        z.writestr("frame_1_data.pkl", fh.getvalue())
+    t = ti.Tissue(1, "old", [])
+    list(t.load(path, type_name="HC"))
+    want = np.array([[255, 1, 0], [0, 0, 1], [255, 255, 1]], np.uint8)
+    np.testing.assert_array_equal(t.get_cell_types(1), want)
+    assert t.get_cells_info(1)["type"].tolist() == [1, 0, 0] and t.type_names == ["HC"]
+    pos = ti.is_positive_for_type(t.get_cell_types(1), 0)
+    np.testing.assert_array_equal(pos, want == 1)                       # SC and invalid pixels are negative for type 0
+    assert not ti.is_positive_for_type(t.get_cell_types(1), 1).any()    # ... and nothing carries bit 1
+
+
+def test_is_positive_for_type_scalar_quirk_and_events_merge(tmp_path):
+    """Upstream clears INVALID (255) only for arrays (ti.py:171-175): a scalar 255 passes every bit test.  Loading an
+    archive twice must not duplicate events, and a missing `source` reads as 'manual' (ti.py:3526-3536)."""
+    import pandas as pd
+    from tissue_image_processing_amd import tissue_info as ti
+    assert ti.is_positive_for_type(255, 0) and ti.is_positive_for_type(np.uint8(255), 3)
+    assert not ti.is_positive_for_type(np.array([255]), 0)[0]
+    assert ti.is_positive_for_type(5, 2) and not ti.is_positive_for_type(5, 1) and ti.is_positive_for_type(5, -1) is False
+    t = ti.Tissue(1, "ev", [])
+    ev = pd.DataFrame([dict(ti.EVENTS_INFO_SPEC, type="division", start_frame=1, source=None),
+                       dict(ti.EVENTS_INFO_SPEC, type="ablation", start_frame=2, source="auto")])
+    t.events = ev
+    out = str(tmp_path / "ev")
+    list(t.save(out))
+    u = ti.Tissue(1, "ev2", [])
+    list(u.load(out + ".seg"))
+    list(u.load(out + ".seg"))
+    assert len(u.events) == 2 and u.events["source"].tolist() == ["manual", "auto"]
+    assert u.events.index.tolist() == [0, 1]

@@ -145,6 +145,35 @@ class DeviceBuffer:
             pass
 
 
+WS_FLAG_TIES, WS_FLAG_TWO_VALUED, WS_FLAG_SERIAL_EXACT, WS_FLAG_SERIAL_FINISH, WS_FLAG_COUNT_SHIFT = 1, 2, 4, 8, 8
+
+
+def set_tuning(name, value=None):
+    """tip_set_tuning: one of the TIP_* hooks of include/tissue_hip.h; value None restores the default.  The library reads
+    the environment once, when it is first used -- later changes of os.environ do not reach it, this call does."""
+    l = load()
+    rc = l.tip_set_tuning(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError("unknown tuning name %r" % (name,))
+
+
+class tuning:
+    """Context manager: with _lib.tuning(TIP_WS_TIES="fast"): ..."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_tuning(k, os.environ.get(k))
+        return False
+
+
 def prof_enable(on=True):
     check(lib().tip_prof_enable(1 if on else 0))
 

@@ -224,7 +224,8 @@ def save_tiff(path, image, metadata=None, axes="", data_type=""):
     """bim.py:160-188.  Upstream hands the array to aicsimageio's OME-TIFF writer; here a self-contained baseline TIFF
     writer stores every (Y, X) plane of the normalised array as one page (little-endian, uncompressed, min-is-black) with
     the axes string and shape in the first page's ImageDescription -- what ImageJ / tifffile / the reference's read_tiff
-    open as a stack.  OME-XML metadata is not written."""
+    open as a stack.  `metadata` with a to_xml() method (or a string) is appended to that description; other objects are
+    reported once as not written."""
     import struct
     image = tiff_normalise(image, data_type)
     if image.dtype == np.float64:
@@ -238,6 +239,17 @@ def save_tiff(path, image, metadata=None, axes="", data_type=""):
     bits = planes.dtype.itemsize * 8
     fmt = 3 if planes.dtype.kind == "f" else (2 if planes.dtype.kind == "i" else 1)
     desc = ("axes=%s shape=%s" % (axes, "x".join(str(v) for v in image.shape))).encode("ascii") + b"\0"
+    if metadata is not None:
+        # upstream hands the OME metadata to aicsimageio's writer; here its XML (if it has one) rides in the description
+        xml = metadata.to_xml() if hasattr(metadata, "to_xml") else (metadata if isinstance(metadata, (str, bytes)) else None)
+        if xml is None:
+            import warnings
+            warnings.warn("save_tiff: metadata of type %s is not written (no OME-XML writer here)" % type(metadata).__name__)
+        else:
+            desc = desc[:-1] + b"\n" + (xml if isinstance(xml, bytes) else xml.encode("utf-8", "replace")) + b"\0"
+    desc += b"\0" * (len(desc) & 1)                       # TIFF 6.0: every IFD starts on a word boundary
+    plane_bytes = rows * cols * planes.dtype.itemsize
+    pad = plane_bytes & 1                                   # (odd-sized uint8 planes)
     if planes.nbytes + planes.shape[0] * 256 + len(desc) >= 2 ** 32:
         raise ValueError("save_tiff: classic TIFF holds less than 4 GiB; split the movie")
     with open(path, "wb") as fh:
@@ -253,13 +265,14 @@ def save_tiff(path, image, metadata=None, axes="", data_type=""):
             if extra:
                 entries.append((270, 2, len(extra), offset + ifd_size))
             entries.sort()
-            nxt = data_at + rows * cols * planes.dtype.itemsize if k + 1 < planes.shape[0] else 0
+            nxt = data_at + plane_bytes + pad if k + 1 < planes.shape[0] else 0
             fh.write(struct.pack("<H", len(entries)))
             for tag, typ, cnt, val in entries:
                 fh.write(struct.pack("<HHII", tag, typ, cnt, val))
             fh.write(struct.pack("<I", nxt))
             fh.write(extra)
             fh.write(planes[k].tobytes())
+            fh.write(b"\0" * pad)
             offset = nxt
     return
 

@@ -1,6 +1,8 @@
 // tip_core.hip -- context, memory, error and profiling plumbing of libtissue_hip.so
 #include "tip_internal.h"
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -106,6 +108,65 @@ void prof_end()
     (void)hipEventRecord(c.recs.back().e1, c.stream);
 }
 
+// ---- tuning table ---------------------------------------------------------------------------------------------------------
+namespace {
+Tuning g_tuning;
+std::once_flag g_tuning_once;
+std::mutex g_tuning_mu;
+
+// one assignment from its textual form (nullptr / "": back to the default); false: unknown name
+bool tuning_assign(Tuning &t, const char *name, const char *value)
+{
+    const Tuning def;
+    const bool unset = !value || !*value;
+    auto flag = [&](int &field, int dflt) { field = unset ? dflt : (strcmp(value, "0") != 0 ? 1 : 0); };
+    auto num = [&](int &field, int dflt) { field = unset ? dflt : atoi(value); };
+    auto pair = [&](int &a, int &b, int da, int db) {
+        a = da; b = db;
+        if (!unset) sscanf(value, "%d,%d", &a, &b);
+    };
+    const std::string n(name ? name : "");
+    if (n == "TIP_WS_TIES") {
+        if (unset) t.ws_ties = def.ws_ties;
+        else t.ws_ties = (!strcmp(value, "fast") || !strcmp(value, "0")) ? 0 : 1;
+    }
+    else if (n == "TIP_WS_TILE") num(t.ws_tile, def.ws_tile);
+    else if (n == "TIP_WS_OPEN") pair(t.ws_open_a, t.ws_open_b, def.ws_open_a, def.ws_open_b);
+    else if (n == "TIP_WS_CERT_FROM") num(t.ws_cert_from, def.ws_cert_from);
+    else if (n == "TIP_WS_NO_SKIP") flag(t.ws_no_skip, 0);
+    else if (n == "TIP_WS_LDS_PAD") num(t.ws_lds_pad, 0);
+    else if (n == "TIP_WS_DEBUG") flag(t.ws_debug, 0);
+    else if (n == "TIP_WS_NO_ENDGAME") flag(t.ws_no_endgame, 0);
+    else if (n == "TIP_WS_NO_WIDE") flag(t.ws_no_wide, 0);
+    else if (n == "TIP_MFMA_BLOCKS_PER_CU") { num(t.mfma_blocks_per_cu, def.mfma_blocks_per_cu); t.mfma_blocks_per_cu = std::max(1, std::min(2, t.mfma_blocks_per_cu)); }
+    else if (n == "TIP_PROJECT_GENERIC") flag(t.project_generic, 0);
+    else if (n == "TIP_PROJECT_UNFUSED_PREBLUR") flag(t.project_unfused_preblur, 0);
+    else if (n == "TIP_PROJECT_UNFUSED_MASK") flag(t.project_unfused_mask, 0);
+    else if (n == "TIP_PROJECT_EXACT_SCORE") flag(t.project_exact_score, 0);
+    else if (n == "TIP_PROJECT_DEBUG") flag(t.project_debug, 0);
+    else if (n == "TIP_FAST_CFG") pair(t.fast_cfg_y, t.fast_cfg_x, def.fast_cfg_y, def.fast_cfg_x);
+    else return false;
+    return true;
+}
+
+const char *const TUNING_NAMES[] = {"TIP_WS_TIES", "TIP_WS_TILE", "TIP_WS_OPEN", "TIP_WS_CERT_FROM", "TIP_WS_NO_SKIP", "TIP_WS_LDS_PAD",
+                                    "TIP_WS_DEBUG", "TIP_WS_NO_ENDGAME", "TIP_WS_NO_WIDE", "TIP_MFMA_BLOCKS_PER_CU", "TIP_PROJECT_GENERIC",
+                                    "TIP_PROJECT_UNFUSED_PREBLUR", "TIP_PROJECT_UNFUSED_MASK", "TIP_PROJECT_EXACT_SCORE", "TIP_PROJECT_DEBUG",
+                                    "TIP_FAST_CFG"};
+
+void tuning_from_env()
+{
+    for (const char *name : TUNING_NAMES)
+        if (const char *e = getenv(name)) tuning_assign(g_tuning, name, e);
+}
+}  // namespace
+
+const Tuning &tuning()
+{
+    std::call_once(g_tuning_once, tuning_from_env);
+    return g_tuning;
+}
+
 int make_taps(Taps &t, const double *w, int n)
 {
     if (n <= 0 || n > 255 || !(n & 1)) return fail(TIP_ERR_ARG, "tap count %d must be odd and <= 255", n);
@@ -190,6 +251,7 @@ int tip_shutdown(void)
         if (b.p) (void)hipFree(b.p);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto &e : c->free_events) (void)hipEventDestroy(e);
+    if (c->edge_event) (void)hipEventDestroy(c->edge_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     g_ctx = nullptr;
@@ -311,6 +373,16 @@ int tip_prof_report(char *buf, size_t n)
     }
     if (buf && n) snprintf(buf, n, "%s", s.c_str());
     return (int)s.size() + 1;
+}
+
+// name: one of the TIP_* tuning names (include/tissue_hip.h); value: its textual form, NULL or "" for the default.
+// The table is read from the environment once, when the library first needs it; afterwards this is the only way in.
+int tip_set_tuning(const char *name, const char *value)
+{
+    (void)tuning();
+    std::lock_guard<std::mutex> lock(g_tuning_mu);
+    if (!tuning_assign(g_tuning, name, value)) return fail(TIP_ERR_ARG, "tip_set_tuning: unknown name %s", name ? name : "(null)");
+    return TIP_OK;
 }
 
 int tip_gaussian_taps(double sigma, double truncate, double *taps, int cap)

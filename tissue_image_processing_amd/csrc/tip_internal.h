@@ -23,6 +23,8 @@ struct Ctx {
     struct Block { void *p; size_t bytes; bool used; };
     std::vector<Block> pool;
     int last_ws_labels = 0;   // marker count of this thread's last watershed (tip_last_watershed_labels)
+    long last_ws_other = 0;   // ... and its number of pixels that are neither the image's minimum nor its maximum
+    hipEvent_t edge_event = nullptr;   // tip_wait_stream / tip_stream_wait_tip
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
@@ -45,6 +47,24 @@ struct WsGuard {                  // frees workspaces at scope exit
 
 void prof_begin(const char *name);
 void prof_end();
+
+// Process-wide tuning / test hooks.  Filled ONCE from the environment (TIP_* variables) when the library is loaded and
+// changed afterwards only through tip_set_tuning(): entry points read plain ints, never the environment.
+struct Tuning {
+    int ws_ties = 1;            // TIP_WS_TIES: 1 = exact (serial (value, age) replay on tie landscapes), 0 = fast (device order)
+    int ws_tile = -1;           // TIP_WS_TILE: everyday tile flavour (-1: the built-in default)
+    int ws_open_a = -1, ws_open_b = -1;   // TIP_WS_OPEN=a,b
+    int ws_cert_from = -1;      // TIP_WS_CERT_FROM
+    int ws_no_skip = 0;         // TIP_WS_NO_SKIP
+    int ws_lds_pad = 0;         // TIP_WS_LDS_PAD
+    int ws_debug = 0;           // TIP_WS_DEBUG
+    int ws_no_endgame = 0, ws_no_wide = 0;   // TIP_WS_NO_ENDGAME / TIP_WS_NO_WIDE (exercise the stall machinery)
+    int mfma_blocks_per_cu = 2; // TIP_MFMA_BLOCKS_PER_CU
+    int project_generic = 0, project_unfused_preblur = 0, project_unfused_mask = 0;
+    int project_exact_score = 0, project_debug = 0;
+    int fast_cfg_y = -1, fast_cfg_x = -1;    // TIP_FAST_CFG=y,x
+};
+const Tuning &tuning();
 
 #define TIP_HIP(call)                                                                             \
     do {                                                                                          \

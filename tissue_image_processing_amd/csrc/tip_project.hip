@@ -590,7 +590,7 @@ static int launch_mfma(const float *in, float *out, int Zs, int Y, int X, const 
     const int tiles_pos = cdiv(AXIS == 1 ? Y : X, MF_TO), tiles_ln = cdiv(AXIS == 1 ? X : Y, MF_LN);
     const int ntiles = tiles_pos * tiles_ln * Zs;
     const int cus = cu_count();
-    static const int per_cu = getenv("TIP_MFMA_BLOCKS_PER_CU") ? std::max(1, std::min(2, atoi(getenv("TIP_MFMA_BLOCKS_PER_CU")))) : 2;
+    const int per_cu = tuning().mfma_blocks_per_cu;
     const int blocks = std::min(ntiles, per_cu * cus);  // persistent blocks, two per CU (LDS: 64 KB each); tuning hook: one
     TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, dim3(blocks), dim3(MF_NW * 64), lds, in, out, Zs, Y, X, t, ntiles,
                tiles_pos, tiles_ln);
@@ -983,7 +983,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         TIP_LAUNCH("percentile95", k_percentile95, dim3(1), dim3(1024), 0, (const unsigned long long *)hist, clip, 0);
     }
 
-    const bool fast = (X % 4 == 0) && !getenv("TIP_PROJECT_GENERIC");
+    const bool fast = (X % 4 == 0) && !tuning().project_generic;
     // P3: (0.5, 1, 1) of the clipped channel -> A_, then P4's z pass (0.5) of that -> B_
     auto short_blur = [&](const uint16_t *src, ClipInfo *ci, float *A_, float *B_) -> int {
         if (fast) {   // register-sliding kernels (each input loaded once per thread)
@@ -1008,7 +1008,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         return correlate1d_dev(A_, B_, 0, Zs, Y, X, 0, k05, 0);
     };
     // bin_size == 1 only needs the z-passed blur (B): the four short passes run as one kernel (tip_preblur.h)
-    const bool fused_pre = fast && bin == 1 && !getenv("TIP_PROJECT_UNFUSED_PREBLUR");
+    const bool fused_pre = fast && bin == 1 && !tuning().project_unfused_preblur;
     if (fused_pre) {
         ShortTaps s05, s1;
         for (int i = 0; i < 8; ++i) { s05.w[i] = i < 3 ? k05.w[i] : 0.0; s1.w[i] = i < 5 ? k1.w[i] : 0.0; }
@@ -1048,7 +1048,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                    zsel_a, zmap, err);
     } else {
     // P4 + P5: (0.5, 30, 30) score and its argmax
-    const bool certified = fast && Zs <= 64 && !manifold && !getenv("TIP_PROJECT_EXACT_SCORE");
+    const bool certified = fast && Zs <= 64 && !manifold && !tuning().project_exact_score;
     if (manifold) {
         // the spiral reads score VALUES (window argmaxes), so it gets the exact score; min_z is not added (sp.py:57)
         if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
@@ -1068,7 +1068,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         const int r = k30.n >> 1;
         {   // fast y pass B -> A, fast x pass A -> D   (B, the exact z-passed volume, is kept for the exact fix-up)
             int cy = FAST_CFG_Y, cx = FAST_CFG_X;
-            if (const char *e = getenv("TIP_FAST_CFG")) sscanf(e, "%d,%d", &cy, &cx);  // tuning hook: NW*100+NP per pass
+            if (tuning().fast_cfg_y >= 0) { cy = tuning().fast_cfg_y; cx = tuning().fast_cfg_x >= 0 ? tuning().fast_cfg_x : cx; }  // tuning hook TIP_FAST_CFG: NW*100+NP per pass
             if ((rc = launch_fast<1>(cy, (const float *)B, A, Zs, Y, X, f30))) return rc;
             if ((rc = launch_fast<2>(cx, (const float *)A, D, Zs, Y, X, f30))) return rc;
         }
@@ -1078,7 +1078,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                    k30, (const int *)unc, (const int *)uncn, bestz);
         TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
                    zsel_a, zmap, err);
-        if (getenv("TIP_PROJECT_DEBUG")) {
+        if (tuning().project_debug) {
             int hn = 0;
             TIP_HIP(hipMemcpyAsync(&hn, uncn, sizeof(int), hipMemcpyDeviceToHost, c.stream));
             TIP_HIP(hipStreamSynchronize(c.stream));
@@ -1101,7 +1101,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         const int32_t *sel = pass == 0 ? zsel : zsel_a;
         unsigned cm = atoh_shift == 0 ? all : (pass == 0 ? (1u << ref_ch) : (all & ~(1u << ref_ch)));
         if (!cm) continue;
-        if (fast && Zs <= 64 && !getenv("TIP_PROJECT_UNFUSED_MASK")) {
+        if (fast && Zs <= 64 && !tuning().project_unfused_mask) {
             // (instantiated per channel count: the per-channel running maxima are registers, 8 channels' worth of them cost
             //  the two-channel case a third of its occupancy)
             const dim3 fgrid(cdiv(X, FT_X), cdiv(Y, FT_Y));

@@ -27,6 +27,24 @@ __global__ void __launch_bounds__(256) k_bias_relu_affine_f32(float *__restrict_
     reinterpret_cast<float4 *>(x)[i] = v;
 }
 
+// ---- the post-network tail (pl.py:167-194) as one submission on the library's stream ------------------------------------
+int rankfilter2d_dev(const void *in, void *out, int dtype, int Y, int X, int ky, int kx, int fp, int border, int is_max);   // tip_label.hip
+int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int32_t *flags_host);                          // tip_watershed.hip
+
+// HC_B = 255 * (p > thr)  (pl.py:168), p read with a row pitch (the un-padded view of the network's output)
+template <typename T>
+__global__ void __launch_bounds__(256) k_tail_threshold(const T *__restrict__ p, long ld, int Y, int X, T thr, double *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < X) out[(long)y * X + x] = p[(long)y * ld + x] > thr ? 255.0 : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_tail_sub(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+
 }  // namespace tip
 
 using namespace tip;
@@ -46,6 +64,76 @@ int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const float *scale
     hipLaunchKernelGGL(k_bias_relu_affine_f32, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, x, bias, scale, shift, n / 4, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TIP_ERR_HIP, "launch bias_relu_affine: %s", hipGetErrorString(e));
+    return TIP_OK;
+}
+
+// Which device does this runtime think `p` lives on?  >= 0: the ordinal; negative: `p` is not a device pointer THIS copy of
+// the HIP runtime knows.  A caller that hands over torch pointers and torch's stream (tip_bias_relu_affine_f32_dev,
+// tip_unet_tail_dev) checks once that torch and this library share one runtime: PyTorch wheels bundle their own
+// libamdhip64, and two loaded runtimes do not know each other's allocations or stream handles.
+int tip_pointer_device(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return TIP_ERR_ARG; }
+    if (a.type != hipMemoryTypeDevice) return TIP_ERR_ARG;
+    return a.device;
+}
+
+// Ordering edges between the calling thread's library stream and a foreign HIP stream (torch's current stream).  Neither
+// blocks the host.  tip_wait_stream: work submitted to the library AFTER the call starts after everything queued on
+// `stream` BEFORE the call -- call it after allocating (from torch's caching allocator) every buffer the library is going
+// to write: the allocator hands out blocks whose previous owner's kernels may still be queued on that stream.
+int tip_wait_stream(void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!c.edge_event) TIP_HIP(hipEventCreateWithFlags(&c.edge_event, hipEventDisableTiming));
+    TIP_HIP(hipEventRecord(c.edge_event, (hipStream_t)stream));
+    TIP_HIP(hipStreamWaitEvent(c.stream, c.edge_event, 0));
+    return TIP_OK;
+}
+
+// ... and the other direction: `stream` waits for everything submitted to the library so far.
+int tip_stream_wait_tip(void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!c.edge_event) TIP_HIP(hipEventCreateWithFlags(&c.edge_event, hipEventDisableTiming));
+    TIP_HIP(hipEventRecord(c.edge_event, c.stream));
+    TIP_HIP(hipStreamWaitEvent((hipStream_t)stream, c.edge_event, 0));
+    return TIP_OK;
+}
+
+// pl.py:167-194 on a device-resident class-0 probability map p (y rows of x values, row pitch ld elements; dtype 0 =
+// float32, 1 = float64): HC_B = 255 (p > thr) -> 5x5 closing (the reference's 101 iterations are idempotent) -> HC = 7x7
+// erosion -> boundary = 5x5 dilation of (closed - HC) -> watershed(boundary, watershed_line=True).  labels (int32) and hc
+// (float64) are caller-owned device buffers of y * x elements.  Everything runs on the library's stream in library
+// workspaces.  The boundary image is {0, 255} by construction; anything else means a corrupted intermediate and is an
+// error, not a slow flood.
+int tip_unet_tail_dev(const void *p, int dtype, long ld, int y, int x, double thr, int32_t *labels, double *hc, int32_t *flags_host)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!p || !labels || !hc || y < 1 || x < 1 || ld < x || (dtype != 0 && dtype != 1)) return fail(TIP_ERR_ARG, "tip_unet_tail_dev: bad arguments");
+    const long n = (long)y * x;
+    WsGuard ws;
+    double *a = ws.get<double>(n), *b = ws.get<double>(n), *d = ws.get<double>(n);
+    if (!a || !b || !d) return TIP_ERR_NOMEM;
+    if (dtype == 0)
+        TIP_LAUNCH("tail_threshold", k_tail_threshold<float>, dim3(cdiv(x, 256), y), dim3(256), 0, (const float *)p, ld, y, x, (float)thr, a);
+    else
+        TIP_LAUNCH("tail_threshold", k_tail_threshold<double>, dim3(cdiv(x, 256), y), dim3(256), 0, (const double *)p, ld, y, x, thr, a);
+    int rc;
+    if ((rc = rankfilter2d_dev(a, b, 1, y, x, 5, 5, 0, 1, 1))) return rc;     // dilation 5x5, reflect
+    if ((rc = rankfilter2d_dev(b, a, 1, y, x, 5, 5, 0, 1, 0))) return rc;     // erosion 5x5 -> closed
+    if ((rc = rankfilter2d_dev(a, hc, 1, y, x, 7, 7, 0, 1, 0))) return rc;    // HC = erosion 7x7
+    TIP_LAUNCH("tail_sub", k_tail_sub, dim3(cdiv(n, 256)), dim3(256), 0, (const double *)a, (const double *)hc, d, n);
+    if ((rc = rankfilter2d_dev(d, b, 1, y, x, 5, 5, 0, 1, 1))) return rc;     // boundary = dilation 5x5
+    int32_t flags = 0;
+    if ((rc = watershed_dev(b, labels, y, x, 1, &flags))) return rc;
+    if (flags_host) *flags_host = flags;
+    if (c.last_ws_other != 0)
+        return fail(TIP_ERR_HIP, "tip_unet_tail_dev: the boundary image is not two-valued (%ld other values): corrupted intermediate", c.last_ws_other);
     return TIP_OK;
 }
 

@@ -11,10 +11,12 @@
 // the states it read certify the outcome (a not-yet-decided neighbour that could still pop earlier makes the pixel
 // wait; a bounded flood of the "pocket" of earlier-keyed undecided pixels proves that nothing can reach it first).
 // Decisions are monotone, so stale reads are merely conservative, and tiles iterate to a local fixed point in LDS.
-// If a round makes no progress the pixel with the globally smallest pop time is committed (always safe), which
-// keeps the result identical to the serial flood for any image whose non-marker pixels carry distinct values.
-// Equal values between non-marker neighbours are ordered by raster index instead of the serial heap's push age:
-// `flags` bit0 reports that such ties were met.
+// If the tile rounds, the per-component endgame and the wide pass all stall (plateaus larger than any certificate), the
+// rest is one serial dependency chain and is finished by the host stage flood_keyed_finish (tip_ws_serial.hip) with the
+// same pop-time rule, which keeps the result identical to the serial flood for any image whose non-marker pixels carry
+// distinct values.  Mode A orders equal values between non-marker neighbours by raster index, the serial heap by push
+// age: `flags` bit0 reports that such ties were met, and unless the caller chose the fast policy (TIP_WS_TIES=fast) such
+// an image is flooded by the exact serial replay flood_exact instead (bit2).
 // Mode B handles two-valued images (pl.py:194 floods a {0,255} boundary image) EXACTLY: the pop order of the equal-keyed
 // markers follows from the array heap's mechanics (tip_heaporder.hip), everything after it is a FIFO, i.e. a
 // breadth-first search in generations whose pixels carry dense ranks (see the mode B section below).
@@ -27,6 +29,8 @@ namespace tip {
 
 int correlate1d_dev(const void *in, void *out, int dtype, int Z, int Y, int X, int axis, const Taps &t, int force);
 int marker_pop_order(const uint8_t *c, long M, uint32_t *order);   // tip_heaporder.hip
+int flood_exact(const double *img, const int32_t *markers, int32_t *labels, int Y, int X);   // tip_ws_serial.hip
+long flood_keyed_finish(const double *img, uint64_t *st, int Y, int X);
 
 // ---- helpers ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long enc_f64(double d)
@@ -56,7 +60,6 @@ struct WsInfo {           // device-resident scalars
     int unfinished, pad_;            // endgame: components whose replay hit the step limit
     int changed_part[64];            // tile / component kernels spread their `changed` adds over 64 words: thousands of
                                      // same-address atomics per launch serialise in L2 (host adds them up)
-    unsigned long long fb_v, fb_k;   // fallback reduction
     unsigned long long dbg_rounds, dbg_tiles, dbg_evals;  // diagnostics (TIP_WS_DEBUG=1)
     unsigned long long dbg_idle, dbg_certs;               // tile instances that decided nothing / that ran a certificate round
     // endgame results (own words: the tile launches that follow the endgame in the same submission must not clobber them)
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
 // is how many tiles a CU keeps in flight (LDS per tile)
 // Two launch flavours: the everyday one certifies pockets of up to 6 cells inside a 3-pixel halo; when a whole
 // launch makes no progress the wide one (12-pixel halo, 48-cell pockets: stuck pockets are thin staircases up to
-// ~10 px long on smooth landscapes) is tried before the global-minimum fallback.
+// ~10 px long on smooth landscapes) is tried before the serial finish (tip_ws_serial.hip).
 constexpr int WT_FAST = 16, WTH_FAST = 64, WH_FAST = 3, WK_FAST = 6;
 constexpr int WT_WIDE = 32, WTH_WIDE = 256, WH_WIDE = 12, WK_WIDE = 48;
 // Everyday tile flavour (index into tile_launch's switch) and the opening (tile launches before / after the early endgame).
@@ -622,80 +625,10 @@ __global__ void __launch_bounds__(WS_THREADS) k_ws_tiles(const double *__restric
     if (dbg && my_evals) atomicAdd(&info->dbg_evals, (unsigned long long)my_evals);
 }
 
-// fallback: the undecided pixel with the globally smallest pop time is always safe to commit
-__device__ __forceinline__ bool ws_heap_key(const double *v, const unsigned long long *st, int Y, int X, int i, T2 &pt)
-{
-    const int y = i / X, x = i % X;
-    const T2 kp{v[i], i};
-    bool has = false;
-    T2 best{0.0, 0};
-    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
-    for (int k = 0; k < 4; ++k) {
-        if (nb[k] < 0) continue;
-        const unsigned long long s = st[nb[k]];
-        if (st_lab(s) > 0) {
-            const int tr = st_tref(s);
-            const T2 tq{v[tr], tr};
-            if (!has || t_lt(tq, best)) { best = tq; has = true; }
-        }
-    }
-    if (!has) return false;
-    pt = t_lt(kp, best) ? best : kp;
-    return true;
-}
-
-__global__ void __launch_bounds__(256) k_ws_fb_min1(const double *__restrict__ v, const unsigned long long *__restrict__ st, int Y,
-                                                    int X, WsInfo *info)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)Y * X || st_lab(st[i]) != 0) return;
-    T2 pt;
-    if (ws_heap_key(v, st, Y, X, (int)i, pt)) atomicMin(&info->fb_v, enc_f64(pt.v));
-}
-
-__global__ void __launch_bounds__(256) k_ws_fb_min2(const double *__restrict__ v, const unsigned long long *__restrict__ st, int Y,
-                                                    int X, WsInfo *info)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)Y * X || st_lab(st[i]) != 0) return;
-    T2 pt;
-    if (ws_heap_key(v, st, Y, X, (int)i, pt) && enc_f64(pt.v) == info->fb_v)
-        atomicMin(&info->fb_k, ((unsigned long long)(unsigned)pt.i << 32) | (unsigned)i);
-}
-
-__global__ void k_ws_fb_commit(const double *__restrict__ v, unsigned long long *__restrict__ st, int Y, int X, WsInfo *info)
-{
-    if (info->fb_k == ~0ULL) return;
-    const int i = (int)(unsigned)(info->fb_k & 0xffffffffULL);
-    const int y = i / X, x = i % X;
-    const T2 kp{v[i], i};
-    const int nb[4] = {y > 0 ? i - X : -1, x > 0 ? i - 1 : -1, x < X - 1 ? i + 1 : -1, y < Y - 1 ? i + X : -1};
-    int s_lab = 0, pull_lab = 0, pull_tr = 0;
-    bool conflict = false, has_pull = false;
-    T2 pull_t{0.0, 0};
-    for (int k = 0; k < 4; ++k) {
-        if (nb[k] < 0) continue;
-        const unsigned long long s = st[nb[k]];
-        const int l = st_lab(s);
-        if (l <= 0) continue;
-        const int tr = st_tref(s);
-        const T2 tq{v[tr], tr};
-        if (t_lt(tq, kp)) {
-            if (s_lab == 0) s_lab = l;
-            else if (s_lab != l) conflict = true;
-        } else if (!has_pull || t_lt(tq, pull_t)) {
-            has_pull = true; pull_t = tq; pull_lab = l; pull_tr = tr;
-        }
-    }
-    if (s_lab != 0) st[i] = pack_st(conflict ? LINE_LAB : s_lab, i);
-    else if (has_pull) st[i] = pack_st(pull_lab, pull_tr);
-    info->changed = 1;
-}
-
 // ---- mode A endgame: what is still undecided when the tile launches stall are stuck pockets and the pixels that
 // wait for them.  Connected components of undecided pixels evolve independently (everything around them is final), so
 // each one is finished by ONE wave running the serial rule -- commit the component's smallest pop time, repeat -- on an
-// LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / global-minimum fallback.
+// LDS copy of the component.  Components larger than END_CAP are left to the wide tile pass / the serial finish.
 constexpr int END_CAP = 512;
 constexpr int END_GRID = 4096;     // blocks of the endgame launch: they stride over the device-side component count
 constexpr int WS_EARLY_BURST = 1;   // the first endgame runs after this many tile bursts (the first has 10 launches), without waiting for a stall
@@ -1100,7 +1033,7 @@ __global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__res
 __global__ void k_ws_info_init(WsInfo *info)
 {
     info->emin = ~0ULL; info->emax = 0ULL; info->n_other = 0; info->ties = 0; info->n_markers = 0;
-    info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->changed = 0; info->undecided = 0; info->unfinished = 0;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0; info->dbg_idle = 0; info->dbg_certs = 0;
     info->end_oversize = 0; info->end_unfinished = 0; info->ncomp = 0; info->ncells = 0; info->und_total = 0; info->front_total = 0;
@@ -1117,7 +1050,7 @@ __global__ void k_ws_end_reset(WsInfo *info)
     for (int q = 0; q < 64; ++q) info->end_part[q] = 0;
 }
 // totals over the tiles' bookkeeping (a tile that sat a launch out keeps its last count, which is still true: only the
-// tile itself decides its interior -- after an endgame or a fallback commit every tile is woken and recounts)
+// tile itself decides its interior -- after an endgame every tile is woken and recounts)
 __global__ void __launch_bounds__(256) k_ws_tile_totals(const int *__restrict__ tile_und, const int *__restrict__ tile_front, int ntiles,
                                                         WsInfo *info)
 {
@@ -1138,7 +1071,7 @@ __global__ void __launch_bounds__(256) k_ws_tile_totals(const int *__restrict__ 
 __global__ void k_ws_iter_reset(WsInfo *info)
 {
     info->und_total = 0; info->front_total = 0;
-    info->changed = 0; info->undecided = 0; info->unfinished = 0; info->fb_v = ~0ULL; info->fb_k = ~0ULL;
+    info->changed = 0; info->undecided = 0; info->unfinished = 0;
     for (int q = 0; q < 64; ++q) info->changed_part[q] = 0;
     info->dbg_rounds = 0; info->dbg_tiles = 0; info->dbg_evals = 0; info->dbg_idle = 0; info->dbg_certs = 0;
 }
@@ -1176,10 +1109,28 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     TIP_HIP(hipStreamSynchronize(s));
     for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
     c.last_ws_labels = h.n_markers;
-    int flags = h.ties ? 1 : 0;
+    c.last_ws_other = (long)h.n_other;
+    int flags = h.ties ? TIP_WS_FLAG_TIES : 0;
     const bool two_valued = h.n_other == 0 && h.emin != h.emax;
+    const Tuning &tune = tuning();
+    if (h.n_markers > 0 && h.ties && !two_valued && tune.ws_ties != 0) {
+        // value ties that are not the two-valued case: the serial (value, age) heap replay (tip_ws_serial.hip) on the
+        // markers found above; one download of image + markers, one upload of the labels
+        flags |= TIP_WS_FLAG_SERIAL_EXACT;
+        TIP_LAUNCH("ws_emit", k_ws_emit, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st, labels, n);
+        std::vector<double> himg((size_t)n);
+        std::vector<int32_t> hmark((size_t)n), hlab((size_t)n);
+        TIP_HIP(hipMemcpyAsync(himg.data(), img, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        TIP_HIP(hipMemcpyAsync(hmark.data(), labels, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        TIP_HIP(hipStreamSynchronize(s));
+        if ((rc = flood_exact(himg.data(), hmark.data(), hlab.data(), Y, X))) return rc;
+        TIP_HIP(hipMemcpyAsync(labels, hlab.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        TIP_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
+        if (flags_host) *flags_host = flags;
+        return TIP_OK;
+    }
     if (h.n_markers > 0 && two_valued) {
-        flags |= 2;  // mode B
+        flags |= TIP_WS_FLAG_TWO_VALUED;  // mode B
         // (a) pop order of the equal-keyed markers: per-marker push counts -> host recurrence (tip_heaporder.hip) -> ranks
         int *mrank = rank, *total_d = &info->n_markers;    // (n_markers was copied out above; reused as the scan's total)
         TIP_LAUNCH("mb_marker_flags", k_mb_marker_flags, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st, isroot, n);
@@ -1255,9 +1206,8 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (h.unfinished != 0) return fail(TIP_ERR_HIP, "watershed: a generation of the two-valued flood did not resolve");
     } else if (h.n_markers > 0) {
         // everyday tile flavour (tuning hook TIP_WS_TILE): interior edge, halo, evaluated margin
-        int variant = WS_TILE_DEFAULT, open_a = WS_OPEN_A, open_b = WS_OPEN_B;
-        if (const char *e = getenv("TIP_WS_TILE")) variant = atoi(e);
-        if (const char *e = getenv("TIP_WS_OPEN")) sscanf(e, "%d,%d", &open_a, &open_b);
+        const int variant = tune.ws_tile >= 0 ? tune.ws_tile : WS_TILE_DEFAULT;
+        const int open_a = tune.ws_open_a >= 0 ? tune.ws_open_a : WS_OPEN_A, open_b = tune.ws_open_b >= 0 ? tune.ws_open_b : WS_OPEN_B;
         if (variant < 0 || variant > 15 || open_a < 1 || open_b < 1 || open_a > 64 || open_b > 64)
             return fail(TIP_ERR_ARG, "watershed: bad TIP_WS_TILE / TIP_WS_OPEN");
         const int WTv = variant == 12 || variant == 13 ? 8 : (variant == 3 || (variant >= 8 && variant <= 11) ? 32 : WT_FAST);
@@ -1272,20 +1222,21 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (!chg || !tile_und || !tile_wst) return TIP_ERR_NOMEM;
         TIP_HIP(hipMemsetAsync(chg, 0, (size_t)2 * ntiles, s));
         TIP_HIP(hipMemsetAsync(tile_wst, 0, (size_t)ntiles * sizeof(int), s));
-        const int cert_from = getenv("TIP_WS_CERT_FROM") ? atoi(getenv("TIP_WS_CERT_FROM")) : WS_CERT_FROM;
-        int *wst_arg = getenv("TIP_WS_NO_SKIP") ? nullptr : tile_wst;
+        const int cert_from = tune.ws_cert_from >= 0 ? tune.ws_cert_from : WS_CERT_FROM;
+        int *wst_arg = tune.ws_no_skip ? nullptr : tile_wst;     // test hook: re-run stuck tiles on every wake-up
         // extra (unused) dynamic LDS per tile block: fewer resident tiles per CU, room for other frames' kernels (tuning hook)
-        const size_t lds_pad = getenv("TIP_WS_LDS_PAD") ? (size_t)atoi(getenv("TIP_WS_LDS_PAD")) : WS_LDS_PAD;     // test hook: re-run stuck tiles on every wake-up
-        int iter = 0, fallbacks = 0;
+        const size_t lds_pad = tune.ws_lds_pad > 0 ? (size_t)tune.ws_lds_pad : WS_LDS_PAD;
+        int iter = 0, crawl = 0;
+        long finished_serially = -1;
         bool wide = false, wide_after_endgame = false;
         int endgames = 0;
         int burst_no = 0;
         bool early_done = false;
         int post_end_burst = -1;   // index of the first burst after the early endgame
-        // test hooks, read once: TIP_WS_DEBUG prints per-burst counters, TIP_WS_NO_ENDGAME / TIP_WS_NO_WIDE exercise the
-        // fallback machinery
-        const int dbg = getenv("TIP_WS_DEBUG") ? 1 : 0;
-        const bool no_endgame = getenv("TIP_WS_NO_ENDGAME") != nullptr, no_wide = getenv("TIP_WS_NO_WIDE") != nullptr;
+        // test hooks (tip_set_tuning): TIP_WS_DEBUG prints per-burst counters, TIP_WS_NO_ENDGAME / TIP_WS_NO_WIDE exercise
+        // the stall machinery
+        const int dbg = tune.ws_debug;
+        const bool no_endgame = tune.ws_no_endgame != 0, no_wide = tune.ws_no_wide != 0;
         int *cursor = nullptr, *cellsbuf = nullptr, *slot = nullptr, *roots = nullptr;   // endgame workspaces
         // one launch of the everyday tiles (activity words ping-pong by launch parity; every block writes its word)
         auto tile_launch = [&](int it) -> int {
@@ -1386,11 +1337,16 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 // else: quiescent already -- the stall handling below
             }
             const bool early_endgame = !early_done && burst_no >= WS_EARLY_BURST && !wide && !no_endgame;
-            if (h.changed > 0 && !early_endgame) { wide = false; continue; }
+            // crawl detector: a plateau of equal values floods in raster order under mode A's static keys -- one serial chain
+            // that the tiles follow at ~16 pixels per launch.  When several bursts in a row decide less than 1/64 of what is
+            // left, the rest goes to the serial finish below instead of thousands of launches.
+            crawl = (h.changed > 0 && h.und_total > 2048 && (long)h.changed * 64 < (long)h.und_total) ? crawl + 1 : 0;
+            if (h.changed > 0 && !early_endgame && crawl < 6) { wide = false; continue; }
             const bool quiescent = h.changed == 0;
             // (after a wide pass the fine tiles' counts are stale -- too large, never too small)
             const long und_total = h.und_total, front_total = h.front_total;
             if (und_total == 0) break;
+            if (crawl >= 6) goto serial_finish;
             // quiescent and no undecided pixel touches a labelled one: what is left is enclosed by lines and stays 0.
             // (After a wide pass the fine tiles' counts are stale, so this shortcut only applies to the fine rounds.)
             if (front_total == 0 && !wide && quiescent) break;
@@ -1412,31 +1368,32 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                     wide = false;
                     continue;
                 }
-                // only oversize components remain: wide pass / global-minimum fallback machinery
+                // only oversize components remain: wide pass, then the serial finish
                 wide_after_endgame = true;
                 wide = true;
                 continue;
             }
             if (!wide && !no_wide) { wide = true; continue; }  // no progress: one wide launch over every tile
             wide = false;
-            // still nothing: pockets too large to certify locally -> commit the pixel with the globally smallest pop time
-            TIP_LAUNCH("ws_iter_reset", k_ws_iter_reset, dim3(1), dim3(1), 0, info);
-            TIP_LAUNCH("ws_fb_min1", k_ws_fb_min1, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
-            TIP_LAUNCH("ws_fb_min2", k_ws_fb_min2, dim3(cdiv(n, 256)), dim3(256), 0, img, (const unsigned long long *)st, Y, X, info);
-            TIP_LAUNCH("ws_fb_commit", k_ws_fb_commit, dim3(1), dim3(1), 0, img, st, Y, X, info);
-            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
-            TIP_HIP(hipStreamSynchronize(s));
-            for (int q = 0; q < 64; ++q) h.changed += h.changed_part[q];
-            if (h.fb_k == ~0ULL) break;  // the remaining pixels are enclosed by lines: they stay 0, as in the serial flood
-            fallbacks++;
-            // wake the tile of the committed pixel (its 3x3 neighbourhood follows through the activity rule)
+        serial_finish:
+            // still nothing: what is left is a serial dependency chain (plateaus larger than any certificate).  One download,
+            // the host stage finishes the flood with the same pop-time rule, one upload -- instead of one committed pixel per
+            // host round trip (which took minutes on a noisy integer image).
             {
-                const int pi = (int)(unsigned)(h.fb_k & 0xffffffffULL);
-                const int t = (pi / X / WTv) * tilesX + (pi % X) / WTv;
-                TIP_HIP(hipMemsetAsync(chg + (size_t)((iter + 1) & 1) * ntiles + t, 1, 1, s));
+                std::vector<double> himg((size_t)n);
+                std::vector<uint64_t> hst((size_t)n);
+                TIP_HIP(hipMemcpyAsync(himg.data(), img, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipMemcpyAsync(hst.data(), st, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+                TIP_HIP(hipStreamSynchronize(s));
+                finished_serially = flood_keyed_finish(himg.data(), hst.data(), Y, X);
+                TIP_HIP(hipMemcpyAsync(st, hst.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+                TIP_HIP(hipStreamSynchronize(s));
             }
+            if (dbg) fprintf(stderr, "ws serial finish: %ld pixels\n", finished_serially);
+            break;
         }
-        flags |= (fallbacks & 0x3fff) << 2;
+        if (finished_serially >= 0)
+            flags |= TIP_WS_FLAG_SERIAL_FINISH | (int)(std::min<long>(finished_serially, 0x7fffff) << TIP_WS_FLAG_COUNT_SHIFT);
     }
     TIP_LAUNCH("ws_emit", k_ws_emit, dim3(cdiv(n, 256)), dim3(256), 0, (const unsigned long long *)st, labels, n);
     if (flags_host) *flags_host = flags;

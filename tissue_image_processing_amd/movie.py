@@ -18,6 +18,8 @@ label-lookup tracker by the trackpy-model linker (ti.py:1881-1933, linking.Frame
 `backend` supplies the per-frame compute so the same driver runs on GPUs (GpuFrameBackend) and, for the
 multi-process CPU tests, on a stand-in backend with the gloo process group.
 """
+import ctypes
+
 import numpy as np
 
 
@@ -96,6 +98,8 @@ class GpuFrameBackend(object):
             import torch
             dev = torch.device("cuda", _lib.device_for_thread() or 0)
             plane = torch.empty((self.Y, self.X), dtype=torch.float64, device=dev)
+            # (the block may still be in use by kernels queued on torch's stream: order the library's copy after them)
+            _lib.check(p.lib.tip_wait_stream(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             _lib.check(p.lib.tip_memcpy_d2d(_lib.dptr(plane.data_ptr()), _lib.dptr(p.d_proj.ptr + p.ref * self.Y * self.X * 8),
                                             self.Y * self.X * 8))
             self.planes[t] = plane

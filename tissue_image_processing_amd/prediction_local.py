@@ -47,6 +47,22 @@ def normalize_channel(image):
     return (clipped - per1) / (per99 - per1)
 
 
+_shared_runtime = {}
+
+
+def shares_runtime_with_torch(t):
+    """True when libtissue_hip.so and torch use ONE HIP runtime for tensor t's device: the library's runtime attributes
+    t's storage to t.device.index.  PyTorch wheels bundle their own libamdhip64; with two runtimes in the process torch's
+    pointers and stream handles mean nothing to the library, and the fused passes that take them must not be used (the torch
+    expressions run instead).  Checked once per device."""
+    idx = t.device.index if t.device.index is not None else 0
+    ok = _shared_runtime.get(idx)
+    if ok is None:
+        ok = _lib.load().tip_pointer_device(_lib.dptr(t.data_ptr())) == idx
+        _shared_runtime[idx] = ok
+    return ok
+
+
 _FILTERS = (128, 256, 512)
 _BN_EPS = 1e-3  # Keras BatchNormalization default
 
@@ -146,7 +162,8 @@ class _UNet(object):
         four torch passes it replaces); otherwise the torch expressions."""
         torch = self.torch
         if (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[0] == 1 and
-                x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("TISSUE_HIP_UNET_TORCH_EPILOGUE") != "1"):
+                x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("TISSUE_HIP_UNET_TORCH_EPILOGUE") != "1"
+                and shares_runtime_with_torch(x)):
             lib = _lib.lib()
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.tip_bias_relu_affine_f32_dev(_lib.dptr(x.data_ptr()), _lib.dptr(bias.data_ptr()),
@@ -325,30 +342,37 @@ class SegmentationPredictor:
 
     def segment_probability(self, p0, thr=0.1, return_device=False):
         """pl.py:167-194 on a device-resident probability map (torch tensor (X, Y)): threshold -> 5x5 closing ->
-        7x7 erosion -> boundary -> watershed.  Returns (labels int32, HC float64) as numpy arrays."""
+        7x7 erosion -> boundary -> watershed, one submission on the library's stream (tip_unet_tail_dev).  Returns
+        (labels int32, HC float64) as numpy arrays, or as torch tensors with return_device=True.
+
+        Stream ordering: the two output tensors come from torch's caching allocator, whose blocks may still be in use by
+        kernels queued on torch's current stream (another worker thread's freed temporaries when the threads share the
+        default stream), and p0 is produced on that stream -- so the library's stream waits for the torch stream AFTER the
+        allocations (tip_wait_stream), and the host waits for the library before torch sees the results."""
         torch = self.torch
         lib = _lib.lib()
+        if p0.dim() != 2:
+            raise ValueError("segment_probability takes a 2-D probability map")
+        if p0.dtype not in (torch.float32, torch.float64):
+            p0 = p0.to(torch.float32)
+        if p0.stride(1) != 1:
+            p0 = p0.contiguous()
+        if not shares_runtime_with_torch(p0):
+            raise _lib.TissueHipError("libtissue_hip.so and torch use different HIP runtimes in this process: import torch before "
+                                      "the first tissue_image_processing_amd call (see INTEGRATION.md)")
         Xn, Yn = int(p0.shape[0]), int(p0.shape[1])
-        hcb = torch.where(p0 > thr, 255.0, 0.0).to(torch.float64).contiguous()
-        a = torch.empty_like(hcb)
-        b = torch.empty_like(hcb)
-        lab = torch.empty((Xn, Yn), dtype=torch.int32, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        P = lambda t: _lib.dptr(t.data_ptr())
-        rf = lib.tip_rankfilter2d_dev
-        _lib.check(rf(P(hcb), P(a), 1, Xn, Yn, 5, 5, 0, 1, 1))        # dilation 5x5 (reflect)
-        _lib.check(rf(P(a), P(b), 1, Xn, Yn, 5, 5, 0, 1, 0))          # erosion 5x5  -> closed (idempotent: once)
-        closed = b
-        hc = torch.empty_like(hcb)
-        _lib.check(rf(P(closed), P(hc), 1, Xn, Yn, 7, 7, 0, 1, 0))    # HC = erosion 7x7
-        _lib.check(lib.tip_sync())
-        bound = closed - hc
-        torch.cuda.current_stream(self.device).synchronize()
-        _lib.check(rf(P(bound), P(a), 1, Xn, Yn, 5, 5, 0, 1, 1))      # boundary = dilation 5x5
+        lab = torch.empty((Xn, Yn), dtype=torch.int32, device=p0.device)
+        hc = torch.empty((Xn, Yn), dtype=torch.float64, device=p0.device)
+        stream = torch.cuda.current_stream(p0.device).cuda_stream
+        _lib.check(lib.tip_wait_stream(ctypes.c_void_p(stream)))
         flags = ctypes.c_int32(0)
-        _lib.check(lib.tip_watershed_f64_dev(P(a), P(lab), Xn, Yn, 1, ctypes.byref(flags)))
-        _lib.check(lib.tip_sync())
+        rc = lib.tip_unet_tail_dev(_lib.dptr(p0.data_ptr()), 0 if p0.dtype == torch.float32 else 1, ctypes.c_long(int(p0.stride(0))),
+                                   Xn, Yn, ctypes.c_double(thr), _lib.dptr(lab.data_ptr()), _lib.dptr(hc.data_ptr()),
+                                   ctypes.byref(flags))
         self.last_flags = flags.value
+        self.last_markers = int(lib.tip_last_watershed_labels())
+        _lib.check(rc)
+        _lib.check(lib.tip_sync())
         if return_device:
             return lab, hc
         return lab.cpu().numpy(), hc.cpu().numpy()

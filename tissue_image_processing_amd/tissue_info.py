@@ -52,8 +52,10 @@ def _type_bits(type):
 
 
 def is_positive_for_type(type, type_index):
-    """ti.py:146-176: is bit `type_index` of the cell-type byte set (INVALID_TYPE_INDEX never is)?  `type_index` may be a
-    pair (types that must be set, types that must be clear).  Arrays in, boolean arrays out; scalars give numpy bools."""
+    """ti.py:146-176: is bit `type_index` of the cell-type byte set?  `type_index` may be a pair (types that must be set,
+    types that must be clear).  Arrays in, boolean arrays out, with INVALID_TYPE_INDEX (255) cells never positive; a SCALAR
+    type is only bit-tested, as upstream (ti.py:171-175 clears invalid cells for arrays only, so a scalar 255 reads as
+    positive for every type -- kept, and pinned by tests/test_io_formats.py)."""
     if isinstance(type_index, tuple):
         must_have, must_lack = type_index
         verdict = np.ones(np.shape(type), dtype=bool)
@@ -66,7 +68,10 @@ def is_positive_for_type(type, type_index):
         return False
     bits = _type_bits(type)
     bit = np.uint8(1 << type_index)
-    return ((bits & bit) == bit) & (bits != INVALID_TYPE_INDEX)
+    hit = (bits & bit) == bit
+    if bits.ndim == 0:
+        return np.bool_(hit)
+    return hit & (bits != INVALID_TYPE_INDEX)
 
 
 def change_type(current_type, type_index, is_positive):
@@ -594,8 +599,9 @@ class TissueHipMixin(object):
         drifts = local_drifts(first_image, second_image, shift[-2], shift[-1], step_size, window_size)
         rows, cols = np.round(cx).astype(int), np.round(cy).astype(int)
         H, W = np.shape(first_image)
-        if rows.size and (rows.max() >= H or cols.max() >= W):
+        if rows.size and (rows.max() >= H or cols.max() >= W or rows.min() < -H or cols.min() < -W):
             raise IndexError("index %d is out of bounds for the %dx%d drift map" % (max(rows.max(), cols.max()), H, W))
+        rows, cols = np.where(rows < 0, rows + H, rows), np.where(cols < 0, cols + W, cols)   # numpy's wrap, as upstream's map[cx, cy]
         dx, dy = sample_local_drift(drifts, rows, cols)
         cx -= dx
         cy -= dy
@@ -755,8 +761,9 @@ class Tissue(TissueHipMixin):
                         self._labels[k] = np.load(raw)
                     elif m.group(2) == "types.npy":
                         types = np.load(raw)
-                        if types.max() <= 2 and types.min() >= 0:          # old version: 0 meant invalid
-                            types[types == 0] = INVALID_TYPE_INDEX
+                        if types.max() <= 2 and types.min() >= 0:          # old single-type version (ti.py:4225-4228):
+                            types[types == 0] = INVALID_TYPE_INDEX           # 0 meant invalid, 2 meant "SC" = negative for
+                            types[types == 2] = 0                            # every type, in this order
                         self._cell_types[k] = types
                     else:
                         info = pd.read_pickle(raw, compression=None)
@@ -767,6 +774,8 @@ class Tissue(TissueHipMixin):
                         self._cells_info[k] = info
                 elif name == "events_data.pkl":
                     self.events = pd.concat([self.events, pd.read_pickle(raw, compression=None)])
+                    self.events["source"] = self.events["source"].fillna("manual")          # ti.py:3526-3536
+                    self.events.drop_duplicates(inplace=True, ignore_index=True)
                 elif name == "drifts.npy":
                     self.drifts = np.load(raw)
                 elif name == "valid_frames.npy":
