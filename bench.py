@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- end-to-end frames/s of the per-frame confocal-stack hot path on MI355X.
 
-One "step" = one pass of the hot path over one synthetic 2048x2048x30 (C=2, uint16) frame that is already
-resident in HBM: surface projection (sp.py:17-85) -> watershed_segmentation (bim.py:446-476) -> cell tables
-(ti.py:880-909).  One process per GPU; frames are independent units, so N GPUs process N frames per step with no
-data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one synthetic 2048x2048x30 (C=2, uint16) frame per GPU that is already resident
+in HBM.  One process per GPU; frames are independent units, so N GPUs process N frames per step with no data-path
+collective (weak scaling).  Rank 0 prints ONE JSON line.
 
-`value` is the classical-segmentation variant (`config.workload` says so).  BASELINE.json's config 3 names the U-Net
-variant (projection -> U-Net (pl.py:124-199) -> threshold / closing / watershed tail -> cell tables): the default run
-times that too, right after the classical leg, and reports it in the same line under "unet" with its MFMA roofline
-(`--workload unet` makes it the headline instead; `--no-unet-leg` skips it).
+`value` (--workload auto) is BASELINE.json's config 3 as written: surface projection (sp.py:17-85) -> U-Net segmentation
+(pl.py:124-199: prepare, network, threshold / closing / erosion / boundary, two-valued watershed) -> cell tables
+(ti.py:880-909).  The classical variant of the same frame (projection -> watershed_segmentation (bim.py:446-476) -> cell
+tables) is timed in the same process and reported under "classical" (`--workload classical` makes it the headline).
+Both legs also report `value_with_pcie`: the same steps with every frame uploaded from pinned host memory and the
+projection + label map fetched back, i.e. what the drop-in functions (host arrays in and out) sustain.
+
+`python bench.py --gpus N` without a launcher environment starts N ranks itself (one process per GPU, RCCL process group
+on 127.0.0.1) and fails if fewer than N devices are visible; under torchrun it is one of the ranks.
 """
 import argparse
 import ctypes
@@ -88,36 +92,158 @@ def algorithmic_dp_ops(kernel, Z, Y, X):
     return None
 
 
-def cpu_baseline_worker(Ys, Xs, Z, workload):
-    """One CPU-baseline sample: the C/numpy oracle (a port of the reference path, single thread like scipy.ndimage) on a
-    crop of the workload; prints the seconds it took."""
+def cpu_baseline_worker(Ys, Xs, Z, workload, threads):
+    """One CPU-baseline sample: the C/numpy oracle (a port of the reference path, single thread like scipy.ndimage /
+    skimage) on a crop of the workload.  For the U-Net workload the network itself is the SAME float32 network run by
+    torch on the host cores (`threads` of them) on a 512^2 crop -- TensorFlow-CPU's role in the reference -- and the tail is
+    the oracle's restatement of pl.py:167-194 (101 closings, as upstream).  Prints the seconds of every stage."""
     from oracle import oracle as orc
     from tissue_image_processing_amd import synthetic
     st = synthetic.make_stack(Z, Ys, Xs, seed=1234)
     t0 = time.perf_counter()
     proj, zmap = orc.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
-    if workload != "projection":
+    t_proj = time.perf_counter() - t0
+    t_seg = t_fwd = 0.0
+    fwd_px = 0
+    if workload == "classical":
+        t1 = time.perf_counter()
         lab = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
         orc.frame_cellinfo(lab)
-    print("CPU_BASELINE_SECONDS %.6f" % (time.perf_counter() - t0))
+        t_seg = time.perf_counter() - t1
+    elif workload == "unet":
+        import torch
+        from tissue_image_processing_amd.prediction_local import _UNet
+        torch.set_num_threads(max(1, threads))
+        net = _UNet(2, "cpu", dtype=torch.float32)
+        n = 512
+        x = torch.from_numpy(np.stack([proj[1][:n, :n].T, proj[0][:n, :n].T])[None].astype(np.float32))
+        x = x / max(float(x.max()), 1.0)
+        net.calibrate_head(x, 0.5)
+        t1 = time.perf_counter()
+        p = net.forward(x)
+        t_fwd = time.perf_counter() - t1
+        fwd_px = n * n
+        t1 = time.perf_counter()
+        lab = orc.closing_tail(p[0, 0].numpy().astype(np.float64))[0]
+        orc.frame_cellinfo(lab)
+        t_seg = (time.perf_counter() - t1) * (Ys * Xs) / float(fwd_px)     # the tail ran on the network's crop
+    print("CPU_BASELINE_SECONDS %.6f %.6f %.6f %d" % (t_proj, t_seg, t_fwd, fwd_px))
 
 
-def cpu_baseline(sample_yx, Z, workload, nproc):
+def cpu_baseline(sample_yx, Z, workload, nproc, threads=1):
     """Runs the sample in `nproc` child processes at once (started BEFORE this process touches the GPU) and returns the
-    list of per-process seconds: nproc = 1 is the single-core figure, nproc = host cores the embarrassingly parallel
-    "N frames on N processes" one (scipy.ndimage / skimage are single-threaded)."""
+    list of per-process (projection s, segmentation s, network s, network pixels): nproc = 1 is the single-process figure,
+    nproc = host cores the embarrassingly parallel "N frames on N processes" one (scipy.ndimage / skimage are
+    single-threaded)."""
     import subprocess
     Ys, Xs = sample_yx
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload]
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload, str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS=str(threads))
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(nproc)]
     secs = []
     for p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("cpu baseline worker failed")
-        secs.append(float([l for l in out.splitlines() if l.startswith("CPU_BASELINE_SECONDS")][0].split()[1]))
+        f = [l for l in out.splitlines() if l.startswith("CPU_BASELINE_SECONDS")][0].split()
+        secs.append((float(f[1]), float(f[2]), float(f[3]), int(f[4])))
     return secs
+
+
+def cpu_baseline_record(Y, X, Z, workload):
+    """cpu_baseline object of the JSON line for `workload` (classical / projection / unet)."""
+    Ys, Xs = min(Y, 1408), min(X, 1408)
+    scale = (Y * X) / float(Ys * Xs)
+    host_cores = os.cpu_count() or 1
+    try:
+        host_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = max(1, min(host_cores, 32)) if workload == "unet" else 1
+
+    def frame_seconds(rec):
+        t_proj, t_seg, t_fwd, fwd_px = rec
+        return (t_proj + t_seg) * scale + (t_fwd * (Y * X) / float(fwd_px) if fwd_px else 0.0)
+
+    one = cpu_baseline((Ys, Xs), Z, workload, 1, threads)[0]
+    sec = frame_seconds(one)
+    rec = {"value": 1.0 / sec, "unit": "frames/s", "cores": threads, "kind": "port", "host_cores": host_cores, "workload": workload,
+           "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle (%s path): projection %.1f s, segmentation + "
+                     "tables %.1f s on one core, scaled by pixel count" % (Ys, Xs, Z, scale, workload, one[0], one[1])}
+    if workload == "unet":
+        rec["sample"] += ("; network = the same float32 U-Net through torch-CPU on %d threads, 512^2 crop %.1f s scaled x%g "
+                          "(%.2f TFLOP/s)" % (threads, one[2], (Y * X) / float(one[3]),
+                                              19.8 * one[3] / (2048.0 * 2048.0) / max(one[2], 1e-9)))
+        rec["stages_s_per_frame"] = {"projection": one[0] * scale, "tail_and_tables": one[1] * scale,
+                                     "network": one[2] * (Y * X) / float(one[3])}
+    else:
+        nproc = max(1, min(host_cores, 16))
+        many = cpu_baseline((Ys, Xs), Z, workload, nproc) if nproc > 1 else [one]
+        slowest = max(frame_seconds(m) for m in many)
+        rec["n_process"] = {"processes": nproc, "value": nproc / slowest, "unit": "frames/s",
+                            "sample": "the same crop in %d processes at once (one frame each), slowest %.1f s per frame" % (nproc, slowest)}
+    return rec
+
+
+# ---- --gpus N without a launcher: this process starts the N ranks ------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Starts N = --gpus child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as torchrun would)
+    BEFORE this process touches the GPU, and exits non-zero when fewer devices are visible.  Rank 0's stdout (the ONE JSON
+    line) is this process's stdout; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("TIP_BENCH_STUB") != "1":
+        import torch
+        have = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d HIP device(s) visible" % (n, have), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    return worst
+
+
+def stub_rank(args, rank, world):
+    """TIP_BENCH_STUB=1: the launcher / process-group / barrier / max-over-ranks plumbing with no GPU behind it (gloo on
+    the CPU, a step is a short sleep) -- what the CPU test of `--gpus N` runs.  Labelled as such in the line it prints."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.tensor([1.0])
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / float(el), "unit": "frames/s",
+                          "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(el) / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub (no GPU: launcher plumbing only)",
+                          "config": {"workload": "stub"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_movie(args, rank, local_rank, world, dist, torch):
@@ -172,56 +298,61 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
-        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default: 64; 16 for --workload movie, whose every frame is a distinct synthetic stack "
-                         "generated on the host and kept in pinned memory)")
-    ap.add_argument("--warmup", type=int, default=8)
+                    help="timed steps of the headline leg (default: 12 for the U-Net workload, 64 for classical / projection, "
+                         "16 for --workload movie, whose every frame is a distinct synthetic stack kept in pinned memory)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 3 for the U-Net workload, else 8)")
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
-    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"],
+                    help="auto = unet = BASELINE config 3 as written (the classical variant rides along as a secondary leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-unet-leg", action="store_true", help="skip the secondary U-Net leg of the default run")
-    ap.add_argument("--unet-steps", type=int, default=9, help="timed steps of the secondary U-Net leg (2 warm-up steps)")
-    ap.add_argument("--include-upload", action="store_true",
-                    help="also time the host->device copy of every frame (pinned host buffers, copied by the worker that "
-                         "then processes the frame, so uploads overlap other workers' kernels); NOT the headline value")
+    ap.add_argument("--no-secondary-leg", "--no-unet-leg", dest="no_secondary", action="store_true",
+                    help="skip the secondary leg (classical under the U-Net headline and vice versa)")
+    ap.add_argument("--secondary-steps", type=int, default=None, help="timed steps of the secondary leg (default 64 classical / 9 U-Net)")
+    ap.add_argument("--no-pcie-leg", action="store_true", help="skip the value_with_pcie repeat (host upload + output fetch per frame)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight per GPU: host threads, each with its own HIP stream and workspaces (the library "
                          "is re-entrant per thread, like the reference's Qt workers); frames are independent units")
     args = ap.parse_args()
+    workload = "unet" if args.workload == "auto" else args.workload
     if args.steps is None:
-        args.steps = 16 if args.workload == "movie" else 64
+        args.steps = {"movie": 16, "unet": 12}.get(workload, 64)
+    if args.warmup is None:
+        args.warmup = 3 if workload == "unet" else 8
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and "RANK" in os.environ and args.gpus > 1:
+        print("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if os.environ.get("TIP_BENCH_STUB") == "1":
+        return stub_rank(args, rank, world)
     Y, X, Z = args.size
     C = 2
 
     # CPU baseline first: its child processes are started before this process initialises the GPU
     cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload != "movie":
-        wl = "classical" if args.workload in ("auto", "unet") else args.workload
-        Ys, Xs = min(Y, 1408), min(X, 1408)
-        scale = (Y * X) / float(Ys * Xs)
-        host_cores = os.cpu_count() or 1
-        try:
-            host_cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            pass
-        one = cpu_baseline((Ys, Xs), Z, wl, 1)[0]
-        nproc = max(1, min(host_cores, 16))
-        many = cpu_baseline((Ys, Xs), Z, wl, nproc) if nproc > 1 else [one]
-        cpu = {"value": 1.0 / (one * scale), "unit": "frames/s", "cores": 1, "kind": "port", "host_cores": host_cores,
-               "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle (%s path), %.1f s on one core, scaled "
-                         "by pixel count" % (Ys, Xs, Z, scale, wl, one),
-               "n_process": {"processes": nproc, "value": nproc / (max(many) * scale), "unit": "frames/s",
-                             "sample": "the same crop in %d processes at once (one frame each), slowest %.1f s" % (nproc, max(many))}}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and workload != "movie":
+        cpu = cpu_baseline_record(Y, X, Z, workload)
+        if workload == "unet" and not args.no_secondary:
+            cpu["classical"] = cpu_baseline_record(Y, X, Z, "classical")
 
+    # MIOpen's exhaustive find ran its naive reference convolutions for ~3 minutes per process (profiles/r02e_*): the fast
+    # find mode picks the same implicit-GEMM solvers in seconds
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     import torch
     import torch.distributed as dist
+    if torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d needs device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     # TIP_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1) walks the RCCL process-group path on a one-GPU box
     use_dist = world > 1 or (os.environ.get("TIP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -232,21 +363,20 @@ def main():
     from tissue_image_processing_amd import _lib, synthetic
     from tissue_image_processing_amd.pipeline import FramePipeline
     _lib.init(local_rank)
-    if args.workload == "movie":
+    if workload == "movie":
         return bench_movie(args, rank, local_rank, world, dist, torch)
     lib = _lib.lib()
-    workload = args.workload
-    if workload == "auto":
-        workload = "classical"
 
     # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
     import threading
     st = synthetic.make_stack(Z, Y, X, seed=100 + rank)
     st_flip = np.ascontiguousarray(st[:, :, :, ::-1])
+    host_frames = [torch.from_numpy(st).pin_memory(), torch.from_numpy(st_flip).pin_memory()]   # the PCIe leg uploads these
     steps_lock = threading.Lock()
 
     class Worker(object):
-        """One frame in flight: own thread, own HIP stream / workspace pool (tip_init per thread), own resident buffers."""
+        """One frame in flight: own thread, own HIP stream / workspace pool (tip_init per thread), own torch stream for the
+        network, own resident buffers."""
 
         def __init__(self, wid, workload):
             self.wid = wid
@@ -257,13 +387,19 @@ def main():
             self.report = {}
             self.error = None
             self.unet_ms = []
+            self.pcie = False
+            self.diag = []           # U-Net leg: (watershed flags, markers) of every step since the last reset
             self.thread = threading.Thread(target=self.run, daemon=True)
             self.thread.start()
             self.wait()  # wait for setup
 
         def run(self):
             try:
-                self.run_inner()
+                if self.workload == "unet":      # the threads do not share torch's default stream: no thread waits for another's network
+                    with torch.cuda.stream(torch.cuda.Stream(device=local_rank)):
+                        self.run_inner()
+                else:
+                    self.run_inner()
             except BaseException as e:      # a dead worker must fail the run, not leave the main thread waiting
                 self.error = e
                 self.done.release()
@@ -284,9 +420,9 @@ def main():
                 pj = self.pipe._proj_t
                 padded, _ = self.predictor.prepare_image(torch.stack([pj[1].T, pj[0].T]))
                 self.predictor.model.calibrate_head(padded, 0.5)
-            self.host = None
-            if args.include_upload:   # pinned host copies of the two frames; the device buffers are re-filled every step
-                self.host = [torch.from_numpy(st).pin_memory(), torch.from_numpy(st_flip).pin_memory()]
+            # pinned landing buffers of the PCIe leg: the projection (C, Y, X) float64 and the label map int32
+            self.out_proj = torch.empty((C, Y, X), dtype=torch.float64).pin_memory()
+            self.out_lab = torch.empty((Y, X), dtype=torch.int32).pin_memory()
             self.done.release()
             while True:
                 self.todo.acquire()
@@ -305,7 +441,11 @@ def main():
                         self.step(i)
                     self.pipe.sync()
                     if self.workload == "unet":
-                        torch.cuda.synchronize()
+                        torch.cuda.current_stream().synchronize()
+                elif kind == "pcie":
+                    self.pcie = bool(arg)
+                elif kind == "diag":
+                    self.diag = []
                 elif kind == "prof":
                     if arg == "on":
                         _lib.prof_reset()
@@ -322,17 +462,26 @@ def main():
 
         def step(self, i):
             pipe = self.pipe
-            if self.host is not None:
-                h = self.host[i % 2]
+            if self.pcie:
+                h = host_frames[i % 2]
                 _lib.check(lib.tip_memcpy_h2d(_lib.dptr(self.frames[i % 2].ptr), ctypes.c_void_p(h.data_ptr()),
                                               ctypes.c_size_t(h.numel() * 2)))
             pipe.project(self.frames[i % 2])
+            lab_ptr = None
             if self.workload == "classical":
                 pipe.segment(0)
                 pipe.cell_tables()
+                lab_ptr = pipe.d_labels.ptr
             elif self.workload == "unet":
                 lab, _ = pipe.segment_unet(self.predictor)
+                self.diag.append((int(self.predictor.last_flags), int(self.predictor.last_markers)))
                 pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
+                lab_ptr = lab.data_ptr()
+            if self.pcie:        # what the drop-in functions hand back: the (C, Y, X) float64 projection and the int32 label map
+                _lib.check(lib.tip_memcpy_d2h(ctypes.c_void_p(self.out_proj.data_ptr()), _lib.dptr(pipe.d_proj.ptr),
+                                              ctypes.c_size_t(C * Y * X * 8)))
+                if lab_ptr is not None:
+                    _lib.check(lib.tip_memcpy_d2h(ctypes.c_void_p(self.out_lab.data_ptr()), _lib.dptr(lab_ptr), ctypes.c_size_t(Y * X * 4)))
 
         def submit(self, job):
             self.jobs.append(job)
@@ -348,9 +497,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(workload, nthreads, steps, warmup):
-        """warmup untimed steps, then exactly `steps` timed steps between barriers; then an isolated pass (ONE frame in
-        flight) whose per-kernel HIP-event durations feed the roofline."""
+    def diag_summary(workers):
+        """U-Net leg: what the watershed of every step since the last reset reported.  Every boundary image must be
+        two-valued (mode B, exact); a serial stage or a tie flag here would mean a corrupted intermediate."""
+        d = [x for w in workers for x in w.diag]
+        if not d:
+            return None
+        fl = [f for f, _ in d]
+        return {"steps": len(d), "flags_seen": sorted(set(f & 0xff for f in fl)),
+                "all_two_valued": all((f & _lib.WS_FLAG_TWO_VALUED) and not (f & (_lib.WS_FLAG_SERIAL_EXACT | _lib.WS_FLAG_SERIAL_FINISH)) for f in fl),
+                "serial_finish_pixels": int(sum(f >> _lib.WS_FLAG_COUNT_SHIFT for f in fl)),
+                "markers_min": int(min(m for _, m in d)), "markers_max": int(max(m for _, m in d))}
+
+    def run_leg(workload, nthreads, steps, warmup, pcie_steps):
+        """warmup untimed steps, then exactly `steps` timed steps between barriers; the same steps again with per-kernel
+        events; an isolated pass (ONE frame in flight) whose per-kernel HIP-event durations feed the roofline; and the
+        PCIe-inclusive repeat."""
         workers = [Worker(w, workload) for w in range(nthreads)]
 
         def run_steps(n, ws=workers):
@@ -370,18 +532,23 @@ def main():
             if rank == 0:
                 print("bench[%s]: %s" % (workload, msg), file=sys.stderr, flush=True)
 
+        diag = {}
         progress("warm-up (%d frames in flight)" % nthreads)
         run_steps(max(warmup, nthreads))
         barrier()
+        diag["warmup"] = diag_summary(workers)
+        all_workers(("diag", None))
         progress("timed region: %d steps" % steps)
         # The timed region runs the product path as a caller would: no per-kernel events (two hipEventRecord per launch cost
-        # the four-frame pipeline 3-5 % of its rate: 275 against 284 frames/s at 64 steps).  The same K steps are then repeated
-        # with the events on -- same threads, same frames in flight -- for `roofline_timed_region`.
+        # the four-frame pipeline 3-5 % of its rate).  The same K steps are then repeated with the events on -- same threads,
+        # same frames in flight -- for `roofline_timed_region`.
         t0 = time.perf_counter()
         run_steps(steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        progress("%.1f frames/s; the same steps again with per-kernel events" % (steps / elapsed))
+        diag["timed"] = diag_summary(workers)
+        all_workers(("diag", None))
+        progress("%.2f frames/s; the same steps again with per-kernel events" % (steps / elapsed))
         all_workers(("prof", "on"))
         barrier()
         t1 = time.perf_counter()
@@ -400,13 +567,29 @@ def main():
         workers[0].submit(("prof", "off")); workers[0].wait()
         iso_report = dict(workers[0].report)
         iso_unet_ms = list(workers[0].unet_ms)
+        diag["instrumented"] = diag_summary(workers)
+        all_workers(("diag", None))
+        pcie_elapsed = None
+        if pcie_steps:
+            progress("PCIe-inclusive repeat: %d steps (upload of every frame from pinned memory, projection + label map fetched)" % pcie_steps)
+            all_workers(("pcie", True))
+            run_steps(nthreads)
+            barrier()
+            t2 = time.perf_counter()
+            run_steps(pcie_steps)
+            barrier()
+            pcie_elapsed = time.perf_counter() - t2
+            all_workers(("pcie", False))
+            diag["pcie"] = diag_summary(workers)
         all_workers(None)
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed, pcie_elapsed or 0.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return dict(elapsed=elapsed, elapsed_events=elapsed_events, timed=timed_reports, iso=iso_report, iso_steps=iso_steps, unet_ms=unet_ms,
-                    iso_unet_ms=iso_unet_ms, nthreads=nthreads, steps=steps, warmup=warmup)
+            elapsed = float(t[0].item())
+            pcie_elapsed = float(t[1].item()) if pcie_steps else None
+        return dict(workload=workload, elapsed=elapsed, elapsed_events=elapsed_events, timed=timed_reports, iso=iso_report,
+                    iso_steps=iso_steps, unet_ms=unet_ms, iso_unet_ms=iso_unet_ms, nthreads=nthreads, steps=steps, warmup=warmup,
+                    pcie_steps=pcie_steps, pcie_elapsed=pcie_elapsed, diag=diag)
 
     def merge(reports):
         rep = {}
@@ -417,10 +600,12 @@ def main():
         return rep
 
     def roofline_of(rep, nframes):
-        """The dominant kernel = the one with the largest time PER FRAME (all its launches of a frame added up).  Its
+        """The dominant LIBRARY kernel = the one with the largest time PER FRAME (all its launches of a frame added up).  Its
         algorithmic bytes are per-frame figures, so achieved = bytes per frame / its time per frame -- for a
-        kernel launched once per frame that is bytes / launch duration; for the watershed's tile kernel (launched ~20 times
+        kernel launched once per frame that is bytes / launch duration; for the watershed's tile kernel (launched ~16 times
         per frame over the same 50 MB job) it is NOT bytes / one launch."""
+        if not rep:
+            return None
         total_kernel_ms = sum(v[1] for v in rep.values())
         name, (cnt, ms) = max(rep.items(), key=lambda kv: kv[1][1])
         per_frame_s = ms / nframes / 1e3
@@ -455,95 +640,131 @@ def main():
                 out_k[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
         return out_k
 
-    def unet_summary(leg):
-        """MFMA roofline of the U-Net forward pass: dense 3x3-conv flops of pl.py:31-72 at the padded size / the forward
-        pass's duration (torch CUDA events on torch's stream around the network only)."""
-        from tissue_image_processing_amd.prediction_local import _UNet, find_desired_shape
-        hp, wp = find_desired_shape(X, Y)
-        flops = _UNet.flops(None, hp, wp)
+    def unet_roofline(leg):
+        """MFMA roofline of the U-Net forward pass, the dominant kernel group of config 3: dense conv flops of pl.py:31-72 at
+        the padded size / the forward pass's duration (events on the stream the network is launched on, around the network
+        only, one frame in flight)."""
+        from tissue_image_processing_amd import prediction_local as plm
+        hp, wp = plm.find_desired_shape(X, Y)
+        flops = plm._UNet.flops(None, hp, wp)
         ms = leg["iso_unet_ms"] or leg["unet_ms"]
         fwd_ms = float(np.median(ms)) if ms else None
-        dt = os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")
-        peak = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}[dt]
-        r = {"bound": "mfma", "dtype": dt, "flops_per_frame": flops, "peak": peak, "unit": "TFLOP/s",
-             "forward_ms": fwd_ms, "achieved": None, "frac": None,
-             "measured": "torch CUDA events around the network's forward pass (MIOpen convolutions), median of %d" % len(ms)}
+        info = plm.unet_arithmetic()
+        r = {"kernel": "unet_forward", "bound": "mfma", "dtype": info["dtype"], "arithmetic": info["arithmetic"],
+             "flops_per_frame": flops, "peak": info["peak_tflops"], "unit": "TFLOP/s", "forward_ms": fwd_ms,
+             "achieved": None, "frac": None, "traffic": None,
+             "measured": "events around the network's forward pass on its stream, isolated pass (one frame in flight), median of %d" % len(ms)}
         if fwd_ms:
             r["achieved"] = flops / (fwd_ms / 1e3) / 1e12
-            r["frac"] = r["achieved"] / peak
+            r["frac"] = r["achieved"] / info["peak_tflops"]
+            if info.get("issued_flops_factor", 1) != 1:
+                r["issued_tflops"] = r["achieved"] * info["issued_flops_factor"]
+                r["issued_frac_of_bf16_peak"] = r["issued_tflops"] / info["issued_peak_tflops"]
         return r
 
+    from tissue_image_processing_amd import prediction_local as plm
     wl_names = {
         "projection": "surface_projection",
         "classical": "surface_projection+watershed_segmentation+cell_tables",
         "unet": "surface_projection+unet_segmentation(%s,random-init,head bias calibrated to 50%% foreground)+threshold/closing/watershed tail+cell_tables"
-                % os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")}
+                % plm.unet_arithmetic()["dtype"]}
 
-    # U-Net variant: three frames in flight -- the network saturates the chip on its own, but the tail's watershed has a
-    # sequential host stage (the heap-order recurrence of mode B) and latency-bound generations that the other frames'
-    # convolutions hide (measured: 5.10 frames/s with two, 5.29 with three)
+    # U-Net variant: three frames in flight -- the network saturates the chip on its own, but the tail's watershed has
+    # latency-bound generations and a short host stage that the other frames' convolutions hide
     unet_threads = max(1, min(int(os.environ.get("TIP_BENCH_UNET_INFLIGHT", "3")), args.inflight))
-    nthreads = max(1, min(args.inflight, args.steps)) if workload != "unet" else min(unet_threads, args.steps)
-    leg = run_leg(workload, nthreads, args.steps, args.warmup)
-    unet_leg = None
-    if workload == "classical" and not args.no_unet_leg and not args.include_upload:
-        unet_leg = run_leg("unet", min(unet_threads, max(1, args.unet_steps)), max(1, args.unet_steps), max(2, unet_threads))
+
+    def threads_for(wl, steps):
+        return max(1, min(unet_threads if wl == "unet" else args.inflight, steps))
+
+    pcie_steps = 0 if args.no_pcie_leg else None
+    main_pcie = pcie_steps if pcie_steps is not None else (6 if workload == "unet" else 24)
+    leg = run_leg(workload, threads_for(workload, args.steps), args.steps, args.warmup, main_pcie)
+    second = None
+    if not args.no_secondary and workload in ("unet", "classical"):
+        wl2 = "classical" if workload == "unet" else "unet"
+        st2 = args.secondary_steps or (64 if wl2 == "classical" else 9)
+        second = run_leg(wl2, threads_for(wl2, st2), st2, 8 if wl2 == "classical" else 3,
+                         pcie_steps if pcie_steps is not None else (24 if wl2 == "classical" else 6))
     del st, st_flip
 
-    if rank == 0:
-        elapsed = leg["elapsed"]
-        roof = roofline_of(leg["iso"], leg["iso_steps"])
-        roof["measured"] = ("HIP events on the library stream, isolated pass of %d steps with ONE frame in flight run right "
-                            "after the timed region (kernels of concurrent frames share the chip in the timed region)"
-                            % leg["iso_steps"])
-        roof_timed = roofline_of(merge(leg["timed"]), args.steps)
-        roof_timed["measured"] = ("HIP events on the library streams over a repeat of the timed region's %d steps with the same %d frames "
-                                  "in flight (%.1f frames/s with the events on; the timed region itself runs without them)"
-                                  % (args.steps, leg["nthreads"], world * args.steps / leg["elapsed_events"]))
-        kernels = kernel_table(leg["iso"], leg["iso_steps"])
-        # the heaviest ARITHMETIC kernels (the sigma-30 score passes) are bound by the FP32 matrix pipe, not by HBM: the
-        # banded-Toeplitz MFMA tiles issue 2 * (32 + 2 * 120) flop per voxel and pass (241 of the 272 products of an output
-        # are non-zero taps; "achieved" counts the issued flops, "useful" the 2 * 241 of a direct correlation); the dense
-        # FP32 MFMA peak equals the FP32 vector peak (256 flop / clk / CU)
+    def leg_object(lg):
+        """Everything one leg measured, as a JSON object."""
+        el = lg["elapsed"]
+        wl = lg["workload"]
+        o = {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, wl_names[wl]), "value": world * lg["steps"] / el, "unit": "frames/s",
+             "steps": lg["steps"], "warmup": lg["warmup"], "ms_per_step": 1e3 * el / lg["steps"],
+             "dtype": "f64" if wl != "unet" else plm.unet_arithmetic()["dtype"], "frames_in_flight_per_gpu": lg["nthreads"],
+             "includes_h2d_upload": False, "kernels": kernel_table(lg["iso"], lg["iso_steps"])}
+        if lg["pcie_elapsed"]:
+            o["value_with_pcie"] = world * lg["pcie_steps"] / lg["pcie_elapsed"]
+            o["with_pcie"] = {"value": o["value_with_pcie"], "unit": "frames/s", "steps": lg["pcie_steps"], "includes_h2d_upload": True,
+                              "d2h_outputs": "projection (C,Y,X) float64 + label map int32 into pinned host buffers",
+                              "h2d_bytes_per_frame": C * Z * Y * X * 2, "d2h_bytes_per_frame": C * Y * X * 8 + Y * X * 4}
+        hb = roofline_of(lg["iso"], lg["iso_steps"])
+        if hb:
+            hb["measured"] = ("HIP events on the library stream, isolated pass of %d steps with ONE frame in flight run right after the "
+                              "timed region (kernels of concurrent frames share the chip in the timed region)" % lg["iso_steps"])
+        rt = roofline_of(merge(lg["timed"]), lg["steps"])
+        if rt:
+            rt["measured"] = ("HIP events on the library streams over a repeat of the timed region's %d steps with the same %d frames in "
+                              "flight (%.1f frames/s with the events on; the timed region itself runs without them)"
+                              % (lg["steps"], lg["nthreads"], world * lg["steps"] / lg["elapsed_events"]))
+        if wl == "unet":
+            o["roofline"] = unet_roofline(lg)
+            o["roofline_library_kernel"] = hb
+            o["watershed_diagnostics"] = lg["diag"]
+        else:
+            o["roofline"] = hb
+        o["roofline_timed_region"] = rt
+        # the heaviest ARITHMETIC kernels of the projection (the sigma-30 score passes) are bound by the FP32 matrix pipe, not
+        # by HBM: the banded-Toeplitz MFMA tiles issue 2 * (32 + 2 * 120) flop per voxel and pass, of which the 2 * 241 of a
+        # direct correlation are useful (the rest multiplies the band's zeros); `frac` is the USEFUL rate over the dense FP32
+        # MFMA peak (= the FP32 vector peak, 256 flop / clk / CU)
         valu = {}
         for kname in ("score_fast_y", "score_fast_x"):
-            if kname in leg["iso"] and leg["iso"][kname][0]:
-                cnt_k, ms_k = leg["iso"][kname]
+            if kname in lg["iso"] and lg["iso"][kname][0]:
+                cnt_k, ms_k = lg["iso"][kname]
                 sec = ms_k / cnt_k / 1e3
-                tf = Z * Y * X * 544.0 / sec / 1e12
-                valu[kname] = {"bound": "mfma_fp32", "achieved": tf, "useful": Z * Y * X * 482.0 / sec / 1e12,
-                               "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
-                               "avg_launch_ms": ms_k / cnt_k,
-                               "note": "default build (TIP_FAST_CFG unset): matrix-core kernels; with a VALU configuration the issued-flop figure does not apply"}
+                useful = Z * Y * X * 482.0 / sec / 1e12
+                valu[kname] = {"bound": "mfma_fp32", "achieved": useful, "issued": Z * Y * X * 544.0 / sec / 1e12,
+                               "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": useful / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
+        o["roofline_valu"] = valu
+        return o
+
+    if rank == 0:
+        head = leg_object(leg)
         out = {
-            "metric": "frames/sec end-to-end (2048^2, z=30)", "value": world * args.steps / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if workload != "unet" else "f32",
-            "data": "synthetic",
-            "config": {"workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, wl_names[workload]),
-                       "value_is": workload, "frames_per_step": world, "frames_in_flight_per_gpu": leg["nthreads"],
-                       "includes_h2d_upload": bool(args.include_upload),
+            "metric": "frames/sec end-to-end (2048^2, z=30)", "value": head["value"], "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": head["workload"], "value_is": workload,
+                       "baseline_config": ("configs[2]: 2048x2048 z=30 single frame, full pipeline (projection -> filter -> U-Net seg -> "
+                                           "watershed/CCL)") if workload == "unet" else "the classical variant of configs[2] (no network)",
+                       "frames_per_step": world, "frames_in_flight_per_gpu": leg["nthreads"], "includes_h2d_upload": False,
                        "parallelism": "frame-sharded dp%d, no data-path collective" % world},
-            "roofline": roof, "roofline_timed_region": roof_timed, "roofline_valu": valu, "kernels": kernels,
+            "value_with_pcie": head.get("value_with_pcie"), "with_pcie": head.get("with_pcie"),
+            "roofline": head["roofline"], "roofline_timed_region": head["roofline_timed_region"], "roofline_valu": head["roofline_valu"],
+            "kernels": head["kernels"],
         }
-        if workload == "unet":
-            out["roofline_unet"] = unet_summary(leg)
-        if unet_leg is not None:
-            ue = unet_leg["elapsed"]
-            out["unet"] = {
-                "workload": "%dx%dx%d_c%d_u16:%s" % (Y, X, Z, C, wl_names["unet"]),
-                "value": world * unet_leg["steps"] / ue, "unit": "frames/s", "steps": unet_leg["steps"],
-                "warmup": unet_leg["warmup"], "ms_per_step": 1e3 * ue / unet_leg["steps"], "dtype": "f32",
-                "frames_in_flight_per_gpu": unet_leg["nthreads"], "roofline": unet_summary(unet_leg),
-                "kernels": kernel_table(unet_leg["iso"], unet_leg["iso_steps"]),
-                "note": "BASELINE config 3 as written; timed right after the classical leg in the same process"}
+        for k in ("roofline_library_kernel", "watershed_diagnostics"):
+            if k in head:
+                out[k] = head[k]
+        if second is not None:
+            out[second["workload"]] = dict(leg_object(second), note="secondary leg, timed right after the headline leg in the same process")
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        wd = leg["diag"] if workload == "unet" else (second["diag"] if second is not None and second["workload"] == "unet" else None)
+        if wd and not all(v is None or v["all_two_valued"] for v in wd.values()):
+            print("bench.py: a U-Net step's boundary image was not flooded by the two-valued mode: %r" % (wd,), file=sys.stderr)
+            if use_dist:
+                dist.destroy_process_group()
+            return 3
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -144,6 +144,28 @@ TIP_API int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const floa
 TIP_API int tip_pointer_device(const void *p);
 TIP_API int tip_wait_stream(void *stream);
 TIP_API int tip_stream_wait_tip(void *stream);
+/* ---- the U-Net's layers (pl.py:31-72) on the bf16 matrix cores with split float32 operands --------------------- */
+/* Activations between layers are `planes` (2 or 3) bf16 images [plane][y][x][channel] whose sum is the float32 value */
+/* (csrc/tip_unet_conv.h has the arithmetic and its error bound).  Every call launches on `stream` (torch's current  */
+/* stream: the buffers are torch tensors) and returns at once.                                                        */
+typedef struct tip_unet_conv_desc {
+    const void *in0, *in1;      /* split activations; in1 (c1 channels) is appended to in0's channels: concatenate   */
+    int c0, c1, h, w, planes;   /* channels (multiples of 16), input grid (multiples of 8 x 32), pieces per value     */
+    const void *weights;        /* packed split weights [tap][cin/16][cout/128][plane][128][16] bf16                  */
+    int ntaps, dy[9], dx[9];    /* taps: input offset (-1, 0, 1) each; Conv2D 3x3: the nine offsets in kernel order   */
+    int cout;                   /* multiple of 128                                                                     */
+    const float *bias, *scale, *shift;   /* scale / shift NULL: bias only (Conv2DTranspose); else bias -> ReLU -> BN */
+    void *out;                  /* [plane][out_h][out_w][cout]; input-grid pixel (y, x) -> (y * sy + oy, x * sx + ox)  */
+    int out_h, out_w, sy, sx, oy, ox;
+} tip_unet_conv_desc;
+TIP_API int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream);
+/* first layer, Conv2D(2 -> 128): float32 (2, h, w) in, weights [9][2][128] float32, exact float32 FMAs               */
+TIP_API int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, const float *bias, const float *scale,
+                                    const float *shift, void *out, int planes, void *stream);
+TIP_API int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, void *out, void *stream);   /* MaxPool2D(2) */
+/* Conv2D(128 -> 2, 1x1) + softmax: float32 (2, npix) out; logits != 0: the pre-softmax values                         */
+TIP_API int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int logits,
+                              void *stream);
 /* pl.py:167-194 after the network, one submission: p = class-0 probability map on the device (y rows of x values, row  */
 /* pitch ld elements; dtype 0 = float32, 1 = float64) -> 255 (p > thr) -> 5x5 closing -> HC = 7x7 erosion -> boundary = */
 /* 5x5 dilation of (closed - HC) -> watershed(watershed_line=True).  labels / hc: caller-owned device buffers (y * x).  */

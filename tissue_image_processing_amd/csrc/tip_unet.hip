@@ -7,6 +7,7 @@
 // the multiply and the add round separately like torch's two kernels): bit-identical, one read + one write instead of four.
 // Runs on the stream the caller names (torch's current stream), so no cross-stream synchronisation is needed.
 #include "tip_internal.h"
+#include "tip_unet_conv.h"
 
 namespace tip {
 
@@ -135,6 +136,93 @@ int tip_unet_tail_dev(const void *p, int dtype, long ld, int y, int x, double th
     if (c.last_ws_other != 0)
         return fail(TIP_ERR_HIP, "tip_unet_tail_dev: the boundary image is not two-valued (%ld other values): corrupted intermediate", c.last_ws_other);
     return TIP_OK;
+}
+
+// ---- the network's layers on split bf16 planes (tip_unet_conv.h).  All of them launch on the stream the caller names
+// (torch's current stream: the buffers are torch tensors), like tip_bias_relu_affine_f32_dev. -----------------------------------
+static int unet_launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TIP_ERR_HIP, "launch %s: %s", what, hipGetErrorString(e));
+    return TIP_OK;
+}
+
+int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!d || !d->in0 || !d->weights || !d->bias || !d->out) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: null pointer");
+    if (d->planes != 2 && d->planes != 3) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: planes must be 2 or 3");
+    if (d->h < UC_TH || d->w < UC_TW || d->h % UC_TH || d->w % UC_TW)
+        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: the grid %dx%d is not a multiple of the %dx%d pixel tile", d->h, d->w, UC_TH, UC_TW);
+    if (d->c0 < UC_KC || d->c0 % UC_KC || d->c1 < 0 || d->c1 % UC_KC || (d->c1 > 0 && !d->in1) || d->cout < UC_BN || d->cout % UC_BN)
+        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: channels (%d + %d -> %d) must be multiples of %d / %d", d->c0, d->c1, d->cout, UC_KC, UC_BN);
+    if (d->ntaps < 1 || d->ntaps > 9 || d->sy < 1 || d->sx < 1 || d->oy < 0 || d->ox < 0 ||
+        (d->h - 1) * d->sy + d->oy >= d->out_h || (d->w - 1) * d->sx + d->ox >= d->out_w)
+        return fail(TIP_ERR_ARG, "tip_unet_conv_dev: bad taps / output mapping");
+    if ((d->scale == nullptr) != (d->shift == nullptr)) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: scale and shift come together");
+    ConvParams p;
+    p.in0 = (const uint16_t *)d->in0; p.in1 = (const uint16_t *)(d->c1 > 0 ? d->in1 : d->in0);
+    p.c0 = d->c0; p.c1 = d->c1; p.H = d->h; p.W = d->w;
+    p.w = (const uint16_t *)d->weights; p.ntaps = d->ntaps;
+    for (int t = 0; t < 9; ++t) {
+        p.dy[t] = t < d->ntaps ? d->dy[t] : 0; p.dx[t] = t < d->ntaps ? d->dx[t] : 0;
+        if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: tap offsets are -1, 0 or 1");
+    }
+    p.cout = d->cout; p.bias = d->bias; p.scale = d->scale; p.shift = d->shift;
+    p.out = (uint16_t *)d->out; p.outH = d->out_h; p.outW = d->out_w; p.sy = d->sy; p.sx = d->sx; p.oy = d->oy; p.ox = d->ox;
+    const dim3 grid((d->h / UC_TH) * (d->w / UC_TW), d->cout / UC_BN);
+    const size_t lds = (size_t)d->planes * UC_HP * UC_ROW + 2 * (size_t)d->planes * UC_BN * UC_ROW;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->planes == 2) {
+        static bool attr2 = false;
+        if (!attr2) { TIP_HIP(hipFuncSetAttribute((const void *)k_unet_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
+        hipLaunchKernelGGL(k_unet_conv<2>, grid, dim3(UC_THREADS), lds, s, p);
+    } else {
+        static bool attr3 = false;
+        if (!attr3) { TIP_HIP(hipFuncSetAttribute((const void *)k_unet_conv<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr3 = true; }
+        hipLaunchKernelGGL(k_unet_conv<3>, grid, dim3(UC_THREADS), lds, s, p);
+    }
+    return unet_launch_check("unet_conv");
+}
+
+int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, const float *bias, const float *scale, const float *shift,
+                            void *out, int planes, void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || ((long)h * w) % 64 || (planes != 2 && planes != 3))
+        return fail(TIP_ERR_ARG, "tip_unet_conv_first_dev: bad arguments");
+    const dim3 grid((unsigned)((long)h * w / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (planes == 2) hipLaunchKernelGGL(k_unet_conv_first<2>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
+    else hipLaunchKernelGGL(k_unet_conv_first<3>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
+    return unet_launch_check("unet_conv_first");
+}
+
+int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, void *out, void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!in || !out || h < 2 || w < 2 || (h & 1) || (w & 1) || ch < 8 || ch % 8 || (planes != 2 && planes != 3))
+        return fail(TIP_ERR_ARG, "tip_unet_pool2_dev: bad arguments");
+    const long n = (long)(h / 2) * (w / 2) * (ch / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (planes == 2) hipLaunchKernelGGL(k_unet_pool2<2>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
+    else hipLaunchKernelGGL(k_unet_pool2<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
+    return unet_launch_check("unet_pool2");
+}
+
+int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int logits, void *stream)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!in || !wgt || !bias || !out || npix < 1 || (planes != 2 && planes != 3)) return fail(TIP_ERR_ARG, "tip_unet_head_dev: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(npix * 8, 256));
+    if (planes == 2) hipLaunchKernelGGL(k_unet_head<2>, grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
+    else hipLaunchKernelGGL(k_unet_head<3>, grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
+    return unet_launch_check("unet_head");
 }
 
 }  // extern "C"

@@ -1,0 +1,357 @@
+// tip_unet_conv.h -- the U-Net's dense convolutions (pl.py:31-72: Conv2D 3x3 'same', Conv2DTranspose 3x3 stride 2 'same') as an
+// implicit GEMM on the bf16 matrix cores with SPLIT float32 operands and float32 accumulation.
+//
+// Arithmetic.  gfx950's float32-input MFMA runs at the float32 VECTOR rate (157 TFLOP/s), 1/16 of the bf16 rate, and has no
+// TF32-like mode.  A float32 value a splits exactly into bf16 pieces a = a0 + a1 (+ a2) + r with a0 = bf16(a), a1 = bf16(a - a0),
+// a2 = bf16(a - a0 - a1): |r| <= 2^-17 |a| with two pieces, 2^-25 |a| with three.  A product of two split values is then a short
+// sum of bf16 x bf16 products, each of which the matrix core forms exactly and accumulates in float32:
+//     two pieces   a b ~ a0 b0 + a0 b1 + a1 b0                              (3 MFMAs; dropped terms <= 2^-15.9 |a b| in total)
+//     three pieces a b ~ a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0      (6 MFMAs; dropped terms <= 2^-23.4 |a b|)
+// so every term of a convolution's dot product carries a relative error below 1.6e-5 (two pieces) resp. 9e-8 (three), on top
+// of the float32 accumulation that any float32 convolution has (~ sqrt(K) 6e-8 for K = 1152 ... 9216 terms: 2e-6 ... 6e-6).
+// Activations travel between layers ALREADY SPLIT -- `planes` bf16 images [plane][y][x][channel]; two planes are 4 bytes per
+// value, exactly a float32 -- so the main loop moves bf16 tiles and does no conversion; the producer's epilogue (bias -> ReLU ->
+// BatchNorm scale / shift, all in float32 on the accumulator) does the split.  Weights are split once when the model is loaded.
+//
+// Decomposition.  out[pixel, n] = sum over taps t and input channels c of in[pixel + (dy_t, dx_t), c] * w[t][c][n]: a GEMM with
+// M = pixels, N = output channels, K = taps * Cin.  A workgroup (256 threads, 4 waves) owns an 8 x 32-pixel tile x 128 output
+// channels; the K loop walks the input channels in chunks of 16 and, inside a chunk, the taps:
+//   * the chunk's (8 + 2) x (32 + 2)-pixel halo tile of the activation is staged ONCE in LDS (zero outside the image) and every
+//     tap reads its shifted window from there -- the nine taps of a 3x3 stencil re-use one staged tile;
+//   * the weights of one (chunk, tap) -- 16 x 128 values per plane -- are double-buffered in LDS, the next step's tile is
+//     fetched into registers while the matrix cores work on the current one;
+//   * a wave computes 64 pixels (two tile rows) x 128 channels: 2 x 4 accumulator tiles of v_mfma_f32_32x32x16_bf16, the 16
+//     channels of a chunk being exactly the K of one MFMA.  LDS rows are padded to 48 bytes so that the 16-lane groups of
+//     ds_read_b128 hit 16 different bank quads (MI355X_MICROARCH.md, LDS table).
+// Two inputs (in0 with c0 channels, then in1 with c1) are read as one concatenated tensor: the decoder's
+// concatenate([upsampled, skip]) (pl.py:52) never exists in memory.  A stride-2 transposed convolution is four such
+// convolutions, one per output parity class, with 1 / 2 / 2 / 4 taps and a strided output (tap lists built by the caller).
+#pragma once
+#include "tip_internal.h"
+
+namespace tip {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int UC_TH = 8, UC_TW = 32;          // pixel tile
+constexpr int UC_BN = 128;                    // output channels per workgroup
+constexpr int UC_KC = 16;                     // input channels per chunk = K of one MFMA
+constexpr int UC_HW = UC_TW + 2, UC_HH = UC_TH + 2, UC_HP = UC_HW * UC_HH;   // halo tile: 34 x 10 = 340 pixels
+constexpr int UC_ROW = 48;                    // bytes per LDS row (16 bf16 = 32 bytes + 16 of padding)
+constexpr int UC_THREADS = 256;
+
+struct ConvParams {
+    const uint16_t *in0, *in1;     // split-plane activations [plane][H][W][C]
+    int c0, c1;                    // channels of in0 / in1 (multiples of 16; c1 = 0 without a second input)
+    int H, W;                      // input grid
+    const uint16_t *w;             // packed weights [tap][chunk][nblk][plane][128][16]
+    int ntaps;
+    int dy[9], dx[9];              // input offset of every tap (-1, 0, 1)
+    int cout;                      // multiple of 128
+    const float *bias, *scale, *shift;   // scale == nullptr: bias only (Conv2DTranspose); else bias -> ReLU -> scale, shift
+    uint16_t *out;                 // [plane][outH][outW][cout]
+    int outH, outW, sy, sx, oy, ox;       // output pixel of input-grid pixel (y, x): (y * sy + oy, x * sx + ox)
+};
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float v)
+{
+    const unsigned b = __float_as_uint(v);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;     // round to nearest even (finite values)
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
+// NPL = bf16 pieces per value (2 or 3)
+template <int NPL>
+__global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(const ConvParams p)
+{
+    constexpr int A_BYTES = NPL * UC_HP * UC_ROW;
+    constexpr int B_BYTES = NPL * UC_BN * UC_ROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sA = smem, *sB = smem + A_BYTES;       // sB: two buffers of B_BYTES
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tilesX = p.W / UC_TW;
+    const int tile = blockIdx.x, ty0 = (tile / tilesX) * UC_TH, tx0 = (tile % tilesX) * UC_TW;
+    const int nblk = blockIdx.y, nblks = p.cout / UC_BN;
+    const int cin = p.c0 + p.c1, nchunks = cin / UC_KC, nsteps = nchunks * p.ntaps;
+    const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
+
+    // ---- staging plans (fixed per thread) ---------------------------------------------------------------------------------
+    // A: NPL * 340 pixels * 2 sixteen-byte pieces
+    constexpr int A_PIECES = NPL * UC_HP * 2, A_PER = (A_PIECES + UC_THREADS - 1) / UC_THREADS;
+    constexpr int B_PIECES = NPL * UC_BN * 2, B_PER = B_PIECES / UC_THREADS;
+    uint4 ra[A_PER], rb[B_PER];
+    auto load_a = [&](int chunk) {
+        const int cbase = chunk * UC_KC;
+        const bool second = cbase >= p.c0;
+        const uint16_t *src = second ? p.in1 : p.in0;
+        const int C = second ? p.c1 : p.c0, cc = second ? cbase - p.c0 : cbase;
+        const long plane_stride = second ? in_plane1 : in_plane0;
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int q = tid + u * UC_THREADS;
+            // (no branch around the load: a clamped address is always valid, the select zeroes what lies outside the image --
+            // hipcc would otherwise wait for every conditional load on its own)
+            const int qq = q < A_PIECES ? q : 0;
+            const int pl = qq / (UC_HP * 2), rem = qq - pl * (UC_HP * 2), px = rem >> 1, half = rem & 1;
+            const int hy = px / UC_HW, hx = px - hy * UC_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+            uint4 v = *reinterpret_cast<const uint4 *>(src + pl * plane_stride + ((long)cy * p.W + cx) * C + cc + half * 8);
+            if (!inside) v = make_uint4(0, 0, 0, 0);
+            ra[u] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int q = tid + u * UC_THREADS;
+            if (q < A_PIECES) {
+                const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, half = rem & 1;
+                *reinterpret_cast<uint4 *>(sA + (pl * UC_HP + px) * UC_ROW + half * 16) = ra[u];
+            }
+        }
+    };
+    auto load_b = [&](int chunk, int tap) {
+        const uint16_t *src = p.w + (((long)tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC);
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) rb[u] = *reinterpret_cast<const uint4 *>(src + (tid + u * UC_THREADS) * 8);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) {
+            const int q = tid + u * UC_THREADS;          // piece q: [plane][n][half]
+            const int row = q >> 1, half = q & 1;
+            *reinterpret_cast<uint4 *>(sB + buf * B_BYTES + row * UC_ROW + half * 16) = rb[u];
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    load_a(0);
+    load_b(0, 0);
+    store_a();
+    store_b(0);
+    __syncthreads();
+
+    const int r = lane & 31, h = lane >> 5;
+    int step = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more_a = chunk + 1 < nchunks;
+        if (more_a) load_a(chunk + 1);
+        for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
+            const bool more_b = step + 1 < nsteps;
+            if (more_b) { const bool wrap = tap + 1 == p.ntaps; load_b(wrap ? chunk + 1 : chunk, wrap ? 0 : tap + 1); }
+            const unsigned char *bbuf = sB + (step & 1) * B_BYTES;
+            const int dy = p.dy[tap], dx = p.dx[tap];
+            bf16x8 fa[2][NPL], fb[4][NPL];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + (pl * UC_HP + px) * UC_ROW + h * 16));
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * UC_BN + n * 32 + r) * UC_ROW + h * 16));
+            // products in order of decreasing magnitude class; same accumulator every 8 MFMAs
+#define UC_PRODUCT(PA, PB)                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[n][PB], acc[m][n], 0, 0, 0);
+            if constexpr (NPL == 3) { UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2) }
+            UC_PRODUCT(1, 0)
+            UC_PRODUCT(0, 1)
+            UC_PRODUCT(0, 0)
+#undef UC_PRODUCT
+            if (more_b) store_b((step + 1) & 1);
+            __syncthreads();
+        }
+        if (more_a) {
+            store_a();          // (every wave passed the barrier that ended the chunk's last tap: nobody reads the old tile)
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: float32 bias [-> ReLU -> scale, shift], split, store -----------------------------------------------------
+    const long out_plane = (long)p.outH * p.outW * p.cout;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int co = nblk * UC_BN + n * 32 + r;
+        const float b = p.bias[co];
+        const float sc = p.scale ? p.scale[co] : 1.f, sh = p.scale ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int y = ty0 + wave * 2 + m;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int x = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[m][n][i] + b;
+                if (p.scale) { v = v > 0.f ? v : 0.f; v = v * sc + sh; }
+                const long o = ((long)(y * p.sy + p.oy) * p.outW + (x * p.sx + p.ox)) * p.cout + co;
+                float rest = v;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned hb = bf16_rne_bits(rest);
+                    p.out[pl * out_plane + o] = (uint16_t)hb;
+                    rest -= bf16_bits_to_f32(hb);
+                }
+            }
+        }
+    }
+}
+
+// ---- first layer: Conv2D(2 -> 128, 3x3) on the float32 (2, H, W) network input --------------------------------------------------
+// K = 18: nothing for the matrix cores; exact float32 FMAs, one wave per 64 pixels x 32 output channels (the wave's lanes share
+// every weight: LDS broadcast), the same epilogue and split as the MFMA kernel.
+template <int NPL>
+__global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict__ in, int H, int W, const float *__restrict__ wgt /* [9][2][128] */,
+                                                         const float *__restrict__ bias, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, uint16_t *__restrict__ out)
+{
+    __shared__ float sw[18 * 128];
+    for (int i = threadIdx.x; i < 18 * 128; i += 256) sw[i] = wgt[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const long pix = (long)blockIdx.x * 64 + lane;
+    const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+    float v[18];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const long o = (long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+        const float a = in[o], b = in[(long)H * W + o];
+        v[2 * t] = inside ? a : 0.f;
+        v[2 * t + 1] = inside ? b : 0.f;
+    }
+    const long plane = (long)H * W * 128;
+    uint16_t *dst = out + pix * 128 + cg * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {          // 8 output channels at a time: one 16-byte store per plane
+        unsigned pk[NPL][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = cg * 32 + g * 8 + j;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) a = __builtin_fmaf(v[k], sw[k * 128 + co], a);
+            a += bias[co];
+            a = a > 0.f ? a : 0.f;
+            a = a * scale[co] + shift[co];
+            float rest = a;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const unsigned hb = bf16_rne_bits(rest);
+                rest -= bf16_bits_to_f32(hb);
+                if (j & 1) pk[pl][j >> 1] |= hb << 16; else pk[pl][j >> 1] = hb;
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            *reinterpret_cast<uint4 *>(dst + pl * plane + g * 8) = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+    }
+}
+
+// value of split element e (0..7) of the 16-byte pieces pc[0..NPL)
+template <int NPL>
+__device__ __forceinline__ float split_value(const uint4 *pc, int e)
+{
+    float v = 0.f;
+#pragma unroll
+    for (int pl = NPL - 1; pl >= 0; --pl) {     // smallest piece first: the sum is exact either way (<= 24 significant bits)
+        const unsigned w = e < 2 ? pc[pl].x : (e < 4 ? pc[pl].y : (e < 6 ? pc[pl].z : pc[pl].w));
+        v += bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+    return v;
+}
+
+// ---- MaxPool2D(2) on split planes: the winner's pieces are copied (the pieces of a value are a function of the value) ---------
+template <int NPL>
+__global__ void __launch_bounds__(256) k_unet_pool2(const uint16_t *__restrict__ in, int H, int W, int C, uint16_t *__restrict__ out)
+{
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Ho * Wo * C8) return;
+    const int c8 = (int)(i % C8);
+    const long op = i / C8;
+    const int xo = (int)(op % Wo), yo = (int)(op / Wo);
+    const long in_plane = (long)H * W * C, out_plane = (long)Ho * Wo * C;
+    uint4 pc[4][NPL];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            pc[k][pl] = *reinterpret_cast<const uint4 *>(in + pl * in_plane + ((long)(2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c8 * 8);
+    unsigned res[NPL][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int best = 0;
+        float bv = split_value<NPL>(pc[0], e);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float v = split_value<NPL>(pc[k], e);
+            if (v > bv) { bv = v; best = k; }
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const uint4 q = best == 0 ? pc[0][pl] : (best == 1 ? pc[1][pl] : (best == 2 ? pc[2][pl] : pc[3][pl]));
+            const unsigned w = e < 2 ? q.x : (e < 4 ? q.y : (e < 6 ? q.z : q.w));
+            const unsigned hb = (e & 1) ? (w >> 16) : (w & 0xffffu);
+            if (e & 1) res[pl][e >> 1] |= hb << 16; else res[pl][e >> 1] = hb;
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+        *reinterpret_cast<uint4 *>(out + pl * out_plane + op * C + c8 * 8) = make_uint4(res[pl][0], res[pl][1], res[pl][2], res[pl][3]);
+}
+
+// ---- head: Conv2D(128 -> 2, 1x1) + softmax over the two classes (pl.py:69), float32 out (2, H, W) -------------------------------
+// eight lanes per pixel, 16 channels each; logits != 0: the pre-softmax values (the bench's head calibration)
+template <int NPL>
+__global__ void __launch_bounds__(256) k_unet_head(const uint16_t *__restrict__ in, long npix, const float *__restrict__ wgt /* [2][128] */,
+                                                   const float *__restrict__ bias, float *__restrict__ out, int logits)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pix = t >> 3;
+    const int part = (int)(t & 7);
+    const long plane = npix * 128;
+    float z0 = 0.f, z1 = 0.f;
+    if (pix < npix) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 pc[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) pc[pl] = *reinterpret_cast<const uint4 *>(in + pl * plane + pix * 128 + part * 16 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = split_value<NPL>(pc, e);
+                const int c = part * 16 + g * 8 + e;
+                z0 = __builtin_fmaf(v, wgt[c], z0);
+                z1 = __builtin_fmaf(v, wgt[128 + c], z1);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) { z0 += __shfl_xor(z0, d, 64); z1 += __shfl_xor(z1, d, 64); }
+    if (pix < npix && part == 0) {
+        z0 += bias[0]; z1 += bias[1];
+        if (logits) { out[pix] = z0; out[npix + pix] = z1; return; }
+        const float m = z0 > z1 ? z0 : z1;
+        const float e0 = __expf(z0 - m), e1 = __expf(z1 - m);
+        const float s = e0 + e1;
+        out[pix] = e0 / s;
+        out[npix + pix] = e1 / s;
+    }
+}
+
+}  // namespace tip

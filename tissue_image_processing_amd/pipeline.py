@@ -72,7 +72,8 @@ class FramePipeline:
         import torch
         if getattr(self, "_proj_t", None) is None:
             raise RuntimeError("FramePipeline(use_torch=True) is needed for the U-Net path")
-        self.sync()
+        # the projection was written on the library's stream: torch's current stream waits for it (no host round trip)
+        _lib.check(self.lib.tip_stream_wait_tip(ctypes.c_void_p(torch.cuda.current_stream(self._proj_t.device).cuda_stream)))
         img = torch.stack([self._proj_t[atoh_channel].T, self._proj_t[zo_channel].T])
         lab, hc = predictor.predict(img, return_device=True)
         self._unet_labels = lab

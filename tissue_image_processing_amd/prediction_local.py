@@ -63,6 +63,42 @@ def shares_runtime_with_torch(t):
     return ok
 
 
+def _unet_mode():
+    """TISSUE_HIP_UNET_ARITH: 'bf16x3' (default: hand-written implicit-GEMM convolutions on the bf16 matrix cores, float32
+    operands split into two bf16 pieces, three products per term, float32 accumulation), 'bf16x6' (three pieces, six
+    products: float32-equivalent to 2^-23) or 'miopen' (PyTorch-ROCm / MIOpen float32 convolutions)."""
+    m = os.environ.get("TISSUE_HIP_UNET_ARITH", "bf16x3")
+    if m not in ("bf16x3", "bf16x6", "miopen"):
+        raise ValueError("TISSUE_HIP_UNET_ARITH must be bf16x3, bf16x6 or miopen")
+    if os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32") != "fp32":
+        m = "miopen"
+    return m
+
+
+def unet_arithmetic():
+    """How the network's convolutions are computed in this process (bench.py reports it with the MFMA roofline)."""
+    m = _unet_mode()
+    if m == "miopen":
+        dt = os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")
+        if dt == "fp32":
+            return {"dtype": "f32", "arithmetic": "float32 convolutions through PyTorch-ROCm / MIOpen (fp32 matrix pipe)", "peak_tflops": 157.3}
+        return {"dtype": dt, "arithmetic": "%s convolutions through PyTorch-ROCm / MIOpen" % dt, "peak_tflops": 2500.0}
+    prods = 3 if m == "bf16x3" else 6
+    return {"dtype": "f32", "peak_tflops": 2500.0 / prods, "issued_flops_factor": prods, "issued_peak_tflops": 2500.0,
+            "arithmetic": "float32 operands split into %d bf16 pieces, %d bf16 MFMA products per term (relative error per term <= %s), "
+                          "float32 accumulation; hand-written implicit-GEMM kernels (csrc/tip_unet_conv.h); peak = dense bf16 MFMA "
+                          "peak / %d" % (2 if prods == 3 else 3, prods, "1.6e-5" if prods == 3 else "9e-8", prods)}
+
+
+class _ConvDesc(ctypes.Structure):
+    """tip_unet_conv_desc of include/tissue_hip.h."""
+    _fields_ = [("in0", ctypes.c_void_p), ("in1", ctypes.c_void_p), ("c0", ctypes.c_int), ("c1", ctypes.c_int), ("h", ctypes.c_int),
+                ("w", ctypes.c_int), ("planes", ctypes.c_int), ("weights", ctypes.c_void_p), ("ntaps", ctypes.c_int),
+                ("dy", ctypes.c_int * 9), ("dx", ctypes.c_int * 9), ("cout", ctypes.c_int), ("bias", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_h", ctypes.c_int),
+                ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int)]
+
+
 _FILTERS = (128, 256, 512)
 _BN_EPS = 1e-3  # Keras BatchNormalization default
 
@@ -195,10 +231,142 @@ class _UNet(object):
         self.p["head.b"][0] += shift
         return shift
 
+    # -- hand-written convolution path (csrc/tip_unet_conv.h) ---------------------------------------------------------------
+    def _split_pack(self, taps, planes):
+        """taps: (T, Cin, Cout) float32 on the device -> packed split weights [T][Cin/16][Cout/128][plane][128][16] bf16."""
+        torch = self.torch
+        T, cin, cout = taps.shape
+        pieces, rest = [], taps.float()
+        for _ in range(planes):
+            h = rest.to(torch.bfloat16)
+            pieces.append(h)
+            rest = rest - h.float()
+        pk = torch.stack(pieces, 0).view(planes, T, cin // 16, 16, cout // 128, 128)
+        return pk.permute(1, 2, 4, 0, 5, 3).contiguous()
+
+    def _hip_weights(self, planes):
+        key = "_hipw%d" % planes
+        if getattr(self, key, None) is not None:
+            return getattr(self, key)
+        torch = self.torch
+        p = self.p
+        hw = {}
+
+        def conv3(name):
+            w = p[name + ".w"].float()                                  # (cout, cin, 3, 3): cross-correlation, tap (ky, kx) reads (y + ky - 1, x + kx - 1)
+            taps = torch.stack([w[:, :, ky, kx].t() for ky in range(3) for kx in range(3)], 0)
+            hw[name] = (self._split_pack(taps, planes), [ky - 1 for ky in range(3) for kx in range(3)], [kx - 1 for ky in range(3) for kx in range(3)])
+
+        def conv_t(name):
+            # conv_transpose2d(stride 2): out[2 i + k] += in[i] w[k], cropped to the first 2N rows / columns.  Even outputs take
+            # k = 0 from i = o / 2 and k = 2 from i = o / 2 - 1, odd outputs k = 1 from i = (o - 1) / 2: four parity classes
+            w = p[name + ".w"].float()                                  # (cin, cout, 3, 3)
+            per_axis = {0: [(0, 0), (2, -1)], 1: [(1, 0)]}             # parity -> [(k, input offset)]
+            for py in (0, 1):
+                for px in (0, 1):
+                    tl = [(ky, dy, kx, dx) for ky, dy in per_axis[py] for kx, dx in per_axis[px]]
+                    taps = torch.stack([w[:, :, ky, kx] for ky, _, kx, _ in tl], 0)
+                    hw["%s.%d%d" % (name, py, px)] = (self._split_pack(taps, planes), [t[1] for t in tl], [t[3] for t in tl])
+
+        for blk in ("d0", "d1", "d2", "mid", "u0", "u1", "u2"):
+            if blk != "d0":
+                conv3(blk + ".c1")
+            conv3(blk + ".c2")
+        for i in range(3):
+            conv_t("u%d.t" % i)
+        w0 = p["d0.c1.w"].float()                                       # (128, 2, 3, 3) -> [tap][ci][cout]
+        hw["first"] = w0.permute(2, 3, 1, 0).reshape(18, 128).contiguous()
+        hw["head"] = p["head.w"].float().reshape(2, 128).contiguous()
+        for k in list(p):
+            if k.endswith((".b", ".s", ".t")) and not k.endswith(".t.w"):
+                hw["f:" + k] = p[k].float().reshape(-1).contiguous()
+        setattr(self, key, hw)
+        return hw
+
+    def hip_path_ok(self, x):
+        """The hand-written kernels tile every level's grid in 8 x 32 pixels: extents that are multiples of 64 x 256."""
+        torch = self.torch
+        return (_unet_mode() != "miopen" and x.is_cuda and self.dtype == torch.float32 and x.shape[0] == 1 and x.shape[1] == 2
+                and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and shares_runtime_with_torch(x))
+
+    def _forward_hip(self, x, logits):
+        torch = self.torch
+        planes = 2 if _unet_mode() == "bf16x3" else 3
+        hw = self._hip_weights(planes)
+        lib = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        H, W = int(x.shape[2]), int(x.shape[3])
+        x = x.to(torch.float32).contiguous()
+        D = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def buf(h, w, c):
+            return torch.empty((planes, h, w, c), dtype=torch.bfloat16, device=x.device)
+
+        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None):
+            wp, dy, dx = hw[name]
+            cout = wp.shape[2] * 128
+            d = _ConvDesc()
+            d.in0, d.c0 = src.data_ptr(), src.shape[3]
+            d.in1, d.c1 = (skip.data_ptr(), skip.shape[3]) if skip is not None else (None, 0)
+            d.h, d.w, d.planes = h, w, planes
+            d.weights, d.ntaps = wp.data_ptr(), len(dy)
+            for i in range(len(dy)):
+                d.dy[i], d.dx[i] = dy[i], dx[i]
+            d.cout = cout
+            if bn is not None:
+                d.bias, d.scale, d.shift = hw["f:" + name + ".b"].data_ptr(), hw["f:" + bn + ".s"].data_ptr(), hw["f:" + bn + ".t"].data_ptr()
+            else:
+                d.bias, d.scale, d.shift = hw["f:" + bias + ".b"].data_ptr(), None, None
+            if out is None:
+                out, oh, ow = buf(h, w, cout), h, w
+            d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = out.data_ptr(), oh, ow, sy, sx, oy, ox
+            _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream))
+            return out
+
+        def double(blk, src, skip, h, w, first=False):
+            if first:
+                a = buf(h, w, 128)
+                _lib.check(lib.tip_unet_conv_first_dev(D(x), h, w, D(hw["first"]), D(hw["f:d0.c1.b"]), D(hw["f:d0.b1.s"]), D(hw["f:d0.b1.t"]),
+                                                       D(a), planes, stream))
+            else:
+                a = conv(blk + ".c1", src, skip, h, w, blk + ".b1")
+            return conv(blk + ".c2", a, None, h, w, blk + ".b2")
+
+        def pool(t, h, w):
+            o = buf(h // 2, w // 2, t.shape[3])
+            _lib.check(lib.tip_unet_pool2_dev(D(t), h, w, int(t.shape[3]), planes, D(o), stream))
+            return o
+
+        with torch.no_grad():
+            skips = []
+            h, w = H, W
+            cur = None
+            for i in range(3):
+                f = double("d%d" % i, cur, None, h, w, first=(i == 0))
+                skips.append(f)
+                cur = pool(f, h, w)
+                h, w = h // 2, w // 2
+            cur = double("mid", cur, None, h, w)
+            for i in range(3):
+                name = "u%d.t" % i
+                cout = hw[name + ".00"][0].shape[2] * 128
+                up = buf(2 * h, 2 * w, cout)
+                for py in (0, 1):
+                    for px in (0, 1):
+                        conv("%s.%d%d" % (name, py, px), cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, oy=py, ox=px, bias=name)
+                h, w = 2 * h, 2 * w
+                cur = double("u%d" % i, up, skips[2 - i], h, w)
+            out = torch.empty((1, 2, H, W), dtype=torch.float32, device=x.device)
+            _lib.check(lib.tip_unet_head_dev(D(cur), ctypes.c_long(H * W), D(hw["head"]), D(hw["f:head.b"]), D(out), planes,
+                                             1 if logits else 0, stream))
+        return out
+
     def forward(self, x, logits=False):
         """x: (1, C, H, W) tensor on the device -> class probabilities (1, 2, H, W) float32."""
         torch = self.torch
         F = torch.nn.functional
+        if self.hip_path_ok(x):
+            return self._forward_hip(x, logits)
         with torch.no_grad():
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             skips = []
