@@ -25,6 +25,7 @@ struct Ctx {
     int last_ws_labels = 0;   // marker count of this thread's last watershed (tip_last_watershed_labels)
     long last_ws_other = 0;   // ... and its number of pixels that are neither the image's minimum nor its maximum
     hipEvent_t edge_event = nullptr;   // tip_wait_stream / tip_stream_wait_tip
+    void *zero_page = nullptr;         // 256 zero bytes on the device (tip_unet_conv_dev)
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;

@@ -171,8 +171,14 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     }
     p.cout = d->cout; p.bias = d->bias; p.scale = d->scale; p.shift = d->shift;
     p.out = (uint16_t *)d->out; p.outH = d->out_h; p.outW = d->out_w; p.sy = d->sy; p.sx = d->sx; p.oy = d->oy; p.ox = d->ox;
+    if (!c.zero_page) {     // source of halo pixels outside the image (the copies go global -> LDS, a register zero cannot be written)
+        TIP_HIP(hipMalloc(&c.zero_page, 256));
+        TIP_HIP(hipMemset(c.zero_page, 0, 256));
+    }
+    p.zeros = (const uint16_t *)c.zero_page;
     const dim3 grid((d->h / UC_TH) * (d->w / UC_TW), d->cout / UC_BN);
-    const size_t lds = (size_t)d->planes * UC_HP * UC_ROW + 2 * (size_t)d->planes * UC_BN * UC_ROW;
+    const int a_per = (d->planes * UC_HP * 2 + UC_THREADS - 1) / UC_THREADS;
+    const size_t lds = 2 * (size_t)a_per * UC_THREADS * 16 + (size_t)UC_NBBUF * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
     if (d->planes == 2) {
         static bool attr2 = false;

@@ -38,8 +38,8 @@ constexpr int UC_TH = 8, UC_TW = 32;          // pixel tile
 constexpr int UC_BN = 128;                    // output channels per workgroup
 constexpr int UC_KC = 16;                     // input channels per chunk = K of one MFMA
 constexpr int UC_HW = UC_TW + 2, UC_HH = UC_TH + 2, UC_HP = UC_HW * UC_HH;   // halo tile: 34 x 10 = 340 pixels
-constexpr int UC_ROW = 48;                    // bytes per LDS row (16 bf16 = 32 bytes + 16 of padding)
 constexpr int UC_THREADS = 256;
+constexpr int UC_NBBUF = 3;                   // weight-tile buffers in LDS (copies run two steps ahead)
 
 struct ConvParams {
     const uint16_t *in0, *in1;     // split-plane activations [plane][H][W][C]
@@ -52,6 +52,7 @@ struct ConvParams {
     const float *bias, *scale, *shift;   // scale == nullptr: bias only (Conv2DTranspose); else bias -> ReLU -> scale, shift
     uint16_t *out;                 // [plane][outH][outW][cout]
     int outH, outW, sy, sx, oy, ox;       // output pixel of input-grid pixel (y, x): (y * sy + oy, x * sx + ox)
+    const uint16_t *zeros;         // >= 16 bytes of zeros on the device: the source of halo pixels outside the image
 };
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float v)
@@ -61,14 +62,36 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float v)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
 
-// NPL = bf16 pieces per value (2 or 3)
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// A counted wait on the vector-memory queue followed by the workgroup barrier.  The asynchronous global -> LDS copies of
+// LATER steps stay in flight across the barrier (a __syncthreads() would drain them: its fence waits for vmcnt(0) while an
+// LDS-DMA is pending), so the count is the number of copy instructions this wave issued AFTER the ones it must see landed.
+template <int N>
+__device__ __forceinline__ void uc_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// NPL = bf16 pieces per value (2 or 3).
+//
+// LDS image (one dynamic array; 16-byte slots):  two activation buffers of A_SLOTS slots -- slot (plane * 340 + pixel) * 2 + sh --
+// and UC_NBBUF weight buffers of NPL * 256 slots -- slot (plane * 128 + n) * 2 + sh.  A row (one pixel / one output channel) is
+// 16 bf16 = 32 bytes = two slots; the two halves of row j are stored SWAPPED when bit 3 of j is set (sh = half ^ ((j >> 3) & 1)):
+// the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} of consecutive rows, one half each) then hit 16
+// different bank quads with unpadded rows, which is what lets the tiles arrive by global_load_lds (a wave's 64 x 16 bytes land
+// in 64 consecutive slots; the swizzle is applied to the per-lane SOURCE address).
 template <int NPL>
 __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(const ConvParams p)
 {
-    constexpr int A_BYTES = NPL * UC_HP * UC_ROW;
-    constexpr int B_BYTES = NPL * UC_BN * UC_ROW;
+    constexpr int A_PIECES = NPL * UC_HP * 2;
+    constexpr int A_PER = (A_PIECES + UC_THREADS - 1) / UC_THREADS;      // copy instructions per thread and chunk (6 / 8)
+    constexpr int A_SLOTS = A_PER * UC_THREADS;                           // padded: every wave issues the same number of copies
+    constexpr int A_BYTES = A_SLOTS * 16;
+    constexpr int B_PER = NPL;                                            // NPL * 256 slots / 256 threads
+    constexpr int B_BYTES = NPL * 256 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sA = smem, *sB = smem + A_BYTES;       // sB: two buffers of B_BYTES
+    unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tilesX = p.W / UC_TW;
     const int tile = blockIdx.x, ty0 = (tile / tilesX) * UC_TH, tx0 = (tile % tilesX) * UC_TW;
@@ -76,55 +99,40 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
     const int cin = p.c0 + p.c1, nchunks = cin / UC_KC, nsteps = nchunks * p.ntaps;
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
 
-    // ---- staging plans (fixed per thread) ---------------------------------------------------------------------------------
-    // A: NPL * 340 pixels * 2 sixteen-byte pieces
-    constexpr int A_PIECES = NPL * UC_HP * 2, A_PER = (A_PIECES + UC_THREADS - 1) / UC_THREADS;
-    constexpr int B_PIECES = NPL * UC_BN * 2, B_PER = B_PIECES / UC_THREADS;
-    uint4 ra[A_PER], rb[B_PER];
-    auto load_a = [&](int chunk) {
+    // ---- copy plans (fixed per thread) ------------------------------------------------------------------------------------
+    // activation slot q = u * 256 + tid: plane, halo pixel, stored half -> image pixel (clamped) and logical half
+    int a_pix[A_PER];           // gy * W + gx of the source pixel, or -1: outside the image / padding slot -> zeros
+    int a_sub[A_PER];           // plane * 2 + logical half
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int q = u * UC_THREADS + tid;
+        const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, sh = rem & 1;
+        const int hy = px / UC_HW, hx = px - hy * UC_HW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_pix[u] = inside ? gy * p.W + gx : -1;
+        a_sub[u] = pl * 2 + (sh ^ ((px >> 3) & 1));
+    }
+    auto copy_a = [&](int chunk, int buf) {
         const int cbase = chunk * UC_KC;
         const bool second = cbase >= p.c0;
         const uint16_t *src = second ? p.in1 : p.in0;
         const int C = second ? p.c1 : p.c0, cc = second ? cbase - p.c0 : cbase;
         const long plane_stride = second ? in_plane1 : in_plane0;
+        lds_byte *dst = (lds_byte *)(sA + buf * A_BYTES + wave * 64 * 16);
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
-            const int q = tid + u * UC_THREADS;
-            // (no branch around the load: a clamped address is always valid, the select zeroes what lies outside the image --
-            // hipcc would otherwise wait for every conditional load on its own)
-            const int qq = q < A_PIECES ? q : 0;
-            const int pl = qq / (UC_HP * 2), rem = qq - pl * (UC_HP * 2), px = rem >> 1, half = rem & 1;
-            const int hy = px / UC_HW, hx = px - hy * UC_HW;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-            uint4 v = *reinterpret_cast<const uint4 *>(src + pl * plane_stride + ((long)cy * p.W + cx) * C + cc + half * 8);
-            if (!inside) v = make_uint4(0, 0, 0, 0);
-            ra[u] = v;
+            const uint16_t *g = a_pix[u] >= 0 ? src + (a_sub[u] >> 1) * plane_stride + (long)a_pix[u] * C + cc + (a_sub[u] & 1) * 8 : p.zeros;
+            __builtin_amdgcn_global_load_lds(g, dst + u * UC_THREADS * 16, 16, 0, 0);
         }
     };
-    auto store_a = [&]() {
+    // weight slot q = u * 256 + tid = (plane u, n = tid / 2, stored half tid & 1)
+    const int b_src = (tid >> 1) * UC_KC + (((tid & 1) ^ ((tid >> 4) & 1))) * 8;      // element offset inside a plane's [128][16] tile
+    auto copy_b = [&](int chunk, int tap, int buf) {
+        const uint16_t *src = p.w + (((long)tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC) + b_src;
+        lds_byte *dst = (lds_byte *)(sB + buf * B_BYTES + wave * 64 * 16);
 #pragma unroll
-        for (int u = 0; u < A_PER; ++u) {
-            const int q = tid + u * UC_THREADS;
-            if (q < A_PIECES) {
-                const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, half = rem & 1;
-                *reinterpret_cast<uint4 *>(sA + (pl * UC_HP + px) * UC_ROW + half * 16) = ra[u];
-            }
-        }
-    };
-    auto load_b = [&](int chunk, int tap) {
-        const uint16_t *src = p.w + (((long)tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC);
-#pragma unroll
-        for (int u = 0; u < B_PER; ++u) rb[u] = *reinterpret_cast<const uint4 *>(src + (tid + u * UC_THREADS) * 8);
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < B_PER; ++u) {
-            const int q = tid + u * UC_THREADS;          // piece q: [plane][n][half]
-            const int row = q >> 1, half = q & 1;
-            *reinterpret_cast<uint4 *>(sB + buf * B_BYTES + row * UC_ROW + half * 16) = rb[u];
-        }
+        for (int u = 0; u < B_PER; ++u) __builtin_amdgcn_global_load_lds(src + u * (UC_BN * UC_KC), dst + u * UC_THREADS * 16, 16, 0, 0);
     };
 
     f32x16 acc[2][4];
@@ -135,36 +143,42 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    load_a(0);
-    load_b(0, 0);
-    store_a();
-    store_b(0);
-    __syncthreads();
+    // prologue: activation chunk 0, weight steps 0 and 1
+    copy_a(0, 0);
+    copy_b(0, 0, 0);
+    if (nsteps > 1) copy_b(1 / p.ntaps, 1 % p.ntaps, 1);
+    uc_wait_barrier<0>();
 
     const int r = lane & 31, h = lane >> 5;
+    const int b_row = r * 2 + (h ^ ((r >> 3) & 1));          // slot of this lane's weight fragment inside a plane's 32 rows
     int step = 0;
+    int nc = 2 / p.ntaps, nt = 2 % p.ntaps;                  // (chunk, tap) of step + 2
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more_a = chunk + 1 < nchunks;
-        if (more_a) load_a(chunk + 1);
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
-            const bool more_b = step + 1 < nsteps;
-            if (more_b) { const bool wrap = tap + 1 == p.ntaps; load_b(wrap ? chunk + 1 : chunk, wrap ? 0 : tap + 1); }
-            const unsigned char *bbuf = sB + (step & 1) * B_BYTES;
+            // copies: the next chunk's activations at the chunk's first tap, the weights of step + 2
+            const bool issue_a = tap == 0 && chunk + 1 < nchunks;
+            const bool issue_b = step + 2 < nsteps;
+            if (issue_a) copy_a(chunk + 1, (chunk + 1) & 1);
+            if (issue_b) copy_b(nc, nt, (step + 2) % UC_NBBUF);
+            if (++nt == p.ntaps) { nt = 0; ++nc; }
+            const unsigned char *abuf = sA + (chunk & 1) * A_BYTES;
+            const unsigned char *bbuf = sB + (step % UC_NBBUF) * B_BYTES;
             const int dy = p.dy[tap], dx = p.dx[tap];
             bf16x8 fa[2][NPL], fb[4][NPL];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
+                const int slot = px * 2 + (h ^ ((px >> 3) & 1));
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + (pl * UC_HP + px) * UC_ROW + h * 16));
+                    fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + (pl * UC_HP * 2 + slot) * 16));
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * UC_BN + n * 32 + r) * UC_ROW + h * 16));
-            // products in order of decreasing magnitude class; same accumulator every 8 MFMAs
+                    fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16));
+            // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
 #define UC_PRODUCT(PA, PB)                                                                                      \
     _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[n][PB], acc[m][n], 0, 0, 0);
@@ -173,12 +187,15 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
             UC_PRODUCT(0, 1)
             UC_PRODUCT(0, 0)
 #undef UC_PRODUCT
-            if (more_b) store_b((step + 1) & 1);
-            __syncthreads();
-        }
-        if (more_a) {
-            store_a();          // (every wave passed the barrier that ended the chunk's last tap: nobody reads the old tile)
-            __syncthreads();
+            // Before the barrier the weights of step + 1 must have landed (issued one step ago, before everything issued in
+            // this step) and, when the next step opens a new chunk, its activations too.  Issue order inside a step is
+            // activations first, weights second, so "at most B_PER outstanding" also covers the activations.
+            const bool need_a_now = issue_a && p.ntaps == 1;
+            if (issue_b) {
+                if (issue_a && !need_a_now) uc_wait_barrier<A_PER + B_PER>(); else uc_wait_barrier<B_PER>();
+            } else {
+                if (issue_a && !need_a_now) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>();
+            }
         }
     }
 
@@ -192,17 +209,18 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int y = ty0 + wave * 2 + m;
+            uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + p.ox) * p.cout + co;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int x = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 float v = acc[m][n][i] + b;
                 if (p.scale) { v = v > 0.f ? v : 0.f; v = v * sc + sh; }
-                const long o = ((long)(y * p.sy + p.oy) * p.outW + (x * p.sx + p.ox)) * p.cout + co;
+                uint16_t *o = orow + (long)(x * p.sx) * p.cout;
                 float rest = v;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
                     const unsigned hb = bf16_rne_bits(rest);
-                    p.out[pl * out_plane + o] = (uint16_t)hb;
+                    o[pl * out_plane] = (uint16_t)hb;
                     rest -= bf16_bits_to_f32(hb);
                 }
             }

@@ -299,6 +299,18 @@ class _UNet(object):
         x = x.to(torch.float32).contiguous()
         D = lambda t: ctypes.c_void_p(t.data_ptr())
 
+        trace = getattr(self, "trace", None)      # tools/unet_layers.py: [(layer, flop, event, event)] per launch
+
+        def timed(name, flop, fn):
+            if trace is None:
+                return fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            trace.append((name, flop, e0, e1))
+            return r
+
         def buf(h, w, c):
             return torch.empty((planes, h, w, c), dtype=torch.bfloat16, device=x.device)
 
@@ -320,21 +332,24 @@ class _UNet(object):
             if out is None:
                 out, oh, ow = buf(h, w, cout), h, w
             d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = out.data_ptr(), oh, ow, sy, sx, oy, ox
-            _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream))
+            timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout, len(dy)), 2.0 * h * w * len(dy) * (d.c0 + d.c1) * cout,
+                  lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream)))
             return out
 
         def double(blk, src, skip, h, w, first=False):
             if first:
                 a = buf(h, w, 128)
-                _lib.check(lib.tip_unet_conv_first_dev(D(x), h, w, D(hw["first"]), D(hw["f:d0.c1.b"]), D(hw["f:d0.b1.s"]), D(hw["f:d0.b1.t"]),
-                                                       D(a), planes, stream))
+                timed("first %dx%d 2->128" % (h, w), 2.0 * h * w * 18 * 128,
+                      lambda: _lib.check(lib.tip_unet_conv_first_dev(D(x), h, w, D(hw["first"]), D(hw["f:d0.c1.b"]), D(hw["f:d0.b1.s"]),
+                                                                     D(hw["f:d0.b1.t"]), D(a), planes, stream)))
             else:
                 a = conv(blk + ".c1", src, skip, h, w, blk + ".b1")
             return conv(blk + ".c2", a, None, h, w, blk + ".b2")
 
         def pool(t, h, w):
             o = buf(h // 2, w // 2, t.shape[3])
-            _lib.check(lib.tip_unet_pool2_dev(D(t), h, w, int(t.shape[3]), planes, D(o), stream))
+            timed("pool %dx%d x%d" % (h, w, t.shape[3]), 0.0,
+                  lambda: _lib.check(lib.tip_unet_pool2_dev(D(t), h, w, int(t.shape[3]), planes, D(o), stream)))
             return o
 
         with torch.no_grad():
@@ -357,8 +372,9 @@ class _UNet(object):
                 h, w = 2 * h, 2 * w
                 cur = double("u%d" % i, up, skips[2 - i], h, w)
             out = torch.empty((1, 2, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(lib.tip_unet_head_dev(D(cur), ctypes.c_long(H * W), D(hw["head"]), D(hw["f:head.b"]), D(out), planes,
-                                             1 if logits else 0, stream))
+            timed("head %dx%d" % (H, W), 2.0 * H * W * 256,
+                  lambda: _lib.check(lib.tip_unet_head_dev(D(cur), ctypes.c_long(H * W), D(hw["head"]), D(hw["f:head.b"]), D(out), planes,
+                                                           1 if logits else 0, stream)))
         return out
 
     def forward(self, x, logits=False):
