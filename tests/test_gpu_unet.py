@@ -156,3 +156,63 @@ def test_fused_conv_epilogue_equals_torch_ops(monkeypatch):
     monkeypatch.setenv("TISSUE_HIP_UNET_TORCH_EPILOGUE", "1")
     plain = net.forward(inp)
     assert float((fused - plain).abs().max()) < 1e-5
+
+
+def test_unet_leg_three_frames_in_flight_every_step_exact():
+    """Three worker threads, each with its own library stream and its own torch stream, run the U-Net leg on 2048^2 frames
+    at the same time (bench.py's arrangement).  EVERY step's watershed must be the two-valued mode and its labels and HC map
+    must equal the oracle's on that step's own class map: the outputs of the tail are torch tensors written by the library's
+    stream, so a missing ordering edge between the two stream domains shows up here as a corrupted boundary image (round 2
+    recorded such a run: profiles/r02e_unet_kernel_stats.csv)."""
+    import threading
+    import torch
+    from oracle import oracle as orc
+    from tissue_image_processing_amd import prediction_local as pl, synthetic, _lib
+    N, STEPS, THREADS = 2048, 2, 3
+    results, errors = {}, []
+
+    def make_image(seed):
+        sites = synthetic.make_sites(N, N, seed=seed)[0]
+        d1, d2, i1 = synthetic._two_nearest(sites, N, N)
+        rng = np.random.default_rng(seed)
+        zo = 3000 * np.exp(-(d2 - d1) ** 2 / 4) + rng.poisson(100, (N, N))
+        atoh = 1500 * (i1 % 3 == 0) + rng.poisson(100, (N, N))
+        return np.stack([atoh, zo]).astype(np.float64)
+
+    images = [make_image(20 + k) for k in range(THREADS)]
+    start = threading.Barrier(THREADS)
+
+    def work(k):
+        try:
+            _lib.init(0)
+            with torch.cuda.stream(torch.cuda.Stream(device=0)):
+                pred = pl.SegmentationPredictor(None, images[k].shape)
+                padded, _ = pred.prepare_image(images[k])
+                pred.model.calibrate_head(padded, 0.5)
+                start.wait()
+                for step in range(STEPS):
+                    padded, npad = pred.prepare_image(images[k])
+                    p0 = pred.model.forward(padded)[0, 0]
+                    junk = [torch.empty((N, N), dtype=torch.float64, device=p0.device).normal_() for _ in range(3)]   # churn the allocator
+                    del junk
+                    lab, hc = pred.segment_probability(p0, return_device=True)
+                    results[(k, step)] = (p0.cpu().numpy(), lab.cpu().numpy(), hc.cpu().numpy(), pred.last_flags)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(THREADS)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == THREADS * STEPS
+    for (k, step), (p0, lab, hc, flags) in sorted(results.items()):
+        assert flags & _lib.WS_FLAG_TWO_VALUED and not (flags & (_lib.WS_FLAG_SERIAL_EXACT | _lib.WS_FLAG_SERIAL_FINISH)), (k, step, flags)
+        closed = orc.erosion(orc.dilation(255.0 * (p0 > np.float32(0.1)), 5), 5)
+        hc_ref = orc.erosion(closed, 7)
+        np.testing.assert_array_equal(hc, hc_ref)
+        ref = orc.watershed(orc.dilation(closed - hc_ref, 5))
+        mism = int((lab != ref).sum())
+        print("thread %d step %d: %d labels, flags %#x, mismatches %d" % (k, step, ref.max(), flags, mism))
+        assert mism == 0

@@ -945,15 +945,20 @@ __global__ void __launch_bounds__(256) k_mb_assign_ranks(unsigned long long *__r
     list[r] = u;
 }
 
-// fate of one pixel of the generation (rank r): true when decided.  A pixel waits while a same-generation neighbour of
-// smaller rank is still pending (its fate decides whether this pixel sees a second label).
+// fate of one pixel of the generation (rank r): true when decided.  When the pixel pops, the neighbours labelled before it
+// are those of earlier generations plus the same-generation neighbours of smaller rank that took a label.  A pending
+// same-generation neighbour q of smaller rank will end as a line (ignored) or with its pusher's label, which is already
+// known (cand[q]): if that label equals the one label this pixel sees, q cannot change the outcome and is not waited for --
+// a pixel only waits for smaller-ranked neighbours that would bring a DIFFERENT label, i.e. across a collision front, where
+// the chains are two pixels long instead of running along the whole front.
 __device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst, const unsigned long long *__restrict__ cand, int p,
                                                int myr, int Y, int X)
 {
     const int y = p / X, x = p - y * X;
     const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
     int l0 = 0;
-    bool diff = false, pending = false;
+    bool diff = false;
+    unsigned wait_mask = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (nb[k] < 0) continue;
@@ -964,10 +969,16 @@ __device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst,
             else if (l != l0) diff = true;
         } else if (l == 0) {
             const int r = st_tref(s);
-            pending |= r != 0 && r < myr;
+            if (r != 0 && r < myr) wait_mask |= 1u << k;
         }
     }
-    if (pending) return false;
+    if (!diff && wait_mask) {       // (two labels already: a line whatever the pending neighbours become)
+        bool pending = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((wait_mask >> k) & 1u) pending |= (int)(unsigned)(cand[nb[k]] & 0xffffffffULL) != l0;
+        if (pending) return false;
+    }
     vst[p] = pack_st(diff ? LINE_LAB : (int)(unsigned)(cand[p] & 0xffffffffULL), myr);
     return true;
 }
