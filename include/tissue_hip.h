@@ -157,6 +157,8 @@ typedef struct tip_unet_conv_desc {
     const float *bias, *scale, *shift;   /* scale / shift NULL: bias only (Conv2DTranspose); else bias -> ReLU -> BN */
     void *out;                  /* [plane][out_h][out_w][cout]; input-grid pixel (y, x) -> (y * sy + oy, x * sx + ox)  */
     int out_h, out_w, sy, sx, oy, ox;
+    void *pool_out;             /* NULL, or [plane][out_h / 2][out_w / 2][cout]: MaxPool2D(2) of the output, written from  */
+                                /* the same registers (Conv2D -> MaxPool2D, pl.py:42-43); needs sy = sx = 1, oy = ox = 0   */
 } tip_unet_conv_desc;
 TIP_API int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream);
 /* first layer, Conv2D(2 -> 128): float32 (2, h, w) in, weights [9][2][128] float32, exact float32 FMAs               */

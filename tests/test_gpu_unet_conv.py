@@ -62,9 +62,12 @@ def test_single_layers_against_float64(planes, arith):
     fb, fs, ft = bias.to(dev), scale.to(dev), shift.to(dev)
     d.bias, d.scale, d.shift = fb.data_ptr(), fs.data_ptr(), ft.data_ptr()
     d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = out.data_ptr(), H, W, 1, 1, 0, 0
+    fused_pool = torch.zeros((planes, H // 2, W // 2, CO), dtype=torch.bfloat16, device=dev)
+    d.pool_out = fused_pool.data_ptr()          # MaxPool2D(2) out of the same epilogue
     _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream))
     torch.cuda.synchronize()
     got = _join(out.cpu()).double()
+    assert torch.equal(_join(fused_pool.cpu()), torch.nn.functional.max_pool2d(_join(out.cpu()).permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0))
     # reference on the values the kernel was given (the split inputs / weights), in float64
     x64 = torch.cat([_join(p0.cpu()), _join(p1.cpu())], 2).double().permute(2, 0, 1)[None]
     w64 = _join(_split(wt, planes)).double()

@@ -176,6 +176,9 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
         TIP_HIP(hipMemset(c.zero_page, 0, 256));
     }
     p.zeros = (const uint16_t *)c.zero_page;
+    p.pool_out = (uint16_t *)d->pool_out;
+    if (d->pool_out && (d->sy != 1 || d->sx != 1 || d->oy != 0 || d->ox != 0 || d->out_h != d->h || d->out_w != d->w))
+        return fail(TIP_ERR_ARG, "tip_unet_conv_dev: pool_out needs the plain output mapping");
     const dim3 grid((d->h / UC_TH) * (d->w / UC_TW), d->cout / UC_BN);
     const int a_per = (d->planes * UC_HP * 2 + UC_THREADS - 1) / UC_THREADS;
     const size_t lds = 2 * (size_t)a_per * UC_THREADS * 16 + (size_t)UC_NBBUF * d->planes * 256 * 16;

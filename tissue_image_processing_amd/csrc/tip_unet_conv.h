@@ -33,6 +33,7 @@ namespace tip {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int UC_TH = 8, UC_TW = 32;          // pixel tile
 constexpr int UC_BN = 128;                    // output channels per workgroup
@@ -53,6 +54,7 @@ struct ConvParams {
     uint16_t *out;                 // [plane][outH][outW][cout]
     int outH, outW, sy, sx, oy, ox;       // output pixel of input-grid pixel (y, x): (y * sy + oy, x * sx + ox)
     const uint16_t *zeros;         // >= 16 bytes of zeros on the device: the source of halo pixels outside the image
+    uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float v)
@@ -92,7 +94,8 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
     constexpr int B_BYTES = NPL * 256 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the copies go to M0 without a waterfall loop)
     const int tilesX = p.W / UC_TW;
     const int tile = blockIdx.x, ty0 = (tile / tilesX) * UC_TH, tx0 = (tile % tilesX) * UC_TW;
     const int nblk = blockIdx.y, nblks = p.cout / UC_BN;
@@ -100,19 +103,8 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
 
     // ---- copy plans (fixed per thread) ------------------------------------------------------------------------------------
-    // activation slot q = u * 256 + tid: plane, halo pixel, stored half -> image pixel (clamped) and logical half
-    int a_pix[A_PER];           // gy * W + gx of the source pixel, or -1: outside the image / padding slot -> zeros
-    int a_sub[A_PER];           // plane * 2 + logical half
-#pragma unroll
-    for (int u = 0; u < A_PER; ++u) {
-        const int q = u * UC_THREADS + tid;
-        const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, sh = rem & 1;
-        const int hy = px / UC_HW, hx = px - hy * UC_HW;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_pix[u] = inside ? gy * p.W + gx : -1;
-        a_sub[u] = pl * 2 + (sh ^ ((px >> 3) & 1));
-    }
+    // activation slot q = u * 256 + tid: plane, halo pixel, stored half -> image pixel and logical half.  Recomputed at every
+    // chunk (a few dozen scalar-ish operations against nine steps of MFMAs): the main loop needs the registers.
     auto copy_a = [&](int chunk, int buf) {
         const int cbase = chunk * UC_KC;
         const bool second = cbase >= p.c0;
@@ -122,7 +114,12 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
         lds_byte *dst = (lds_byte *)(sA + buf * A_BYTES + wave * 64 * 16);
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
-            const uint16_t *g = a_pix[u] >= 0 ? src + (a_sub[u] >> 1) * plane_stride + (long)a_pix[u] * C + cc + (a_sub[u] & 1) * 8 : p.zeros;
+            const int q = u * UC_THREADS + tid;
+            const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, half = (rem & 1) ^ ((px >> 3) & 1);
+            const int hy = px / UC_HW, hx = px - hy * UC_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const uint16_t *g = inside ? src + pl * plane_stride + ((long)gy * p.W + gx) * C + cc + half * 8 : p.zeros;
             __builtin_amdgcn_global_load_lds(g, dst + u * UC_THREADS * 16, 16, 0, 0);
         }
     };
@@ -153,16 +150,17 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
     const int b_row = r * 2 + (h ^ ((r >> 3) & 1));          // slot of this lane's weight fragment inside a plane's 32 rows
     int step = 0;
     int nc = 2 / p.ntaps, nt = 2 % p.ntaps;                  // (chunk, tap) of step + 2
+    int buf0 = 0, buf1 = 1, buf2 = 2;                        // weight buffers of steps s, s + 1, s + 2 (no division in the loop)
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
             // copies: the next chunk's activations at the chunk's first tap, the weights of step + 2
             const bool issue_a = tap == 0 && chunk + 1 < nchunks;
             const bool issue_b = step + 2 < nsteps;
             if (issue_a) copy_a(chunk + 1, (chunk + 1) & 1);
-            if (issue_b) copy_b(nc, nt, (step + 2) % UC_NBBUF);
+            if (issue_b) copy_b(nc, nt, buf2);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
             const unsigned char *abuf = sA + (chunk & 1) * A_BYTES;
-            const unsigned char *bbuf = sB + (step % UC_NBBUF) * B_BYTES;
+            const unsigned char *bbuf = sB + buf0 * B_BYTES;
             const int dy = p.dy[tap], dx = p.dx[tap];
             bf16x8 fa[2][NPL], fb[4][NPL];
 #pragma unroll
@@ -196,14 +194,46 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
             } else {
                 if (issue_a && !need_a_now) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>();
             }
+            { const int t0 = buf0; buf0 = buf1; buf1 = buf2; buf2 = t0; }
         }
     }
 
     // ---- epilogue: float32 bias [-> ReLU -> scale, shift], split, store -----------------------------------------------------
+    // A lane holds ONE output channel (r) of 16 pixels per accumulator tile.  Adjacent lanes (channels r, r ^ 1) trade one value
+    // of each register pair (x, x + 1) through a DPP swap, so that every lane stores two adjacent channels of one pixel: 4-byte
+    // stores, half as many as one per value.  With pool_out set (Conv2D followed by MaxPool2D(2), pl.py:42-43) the 2 x 2 window of
+    // a pooled pixel -- rows 2w, 2w + 1 of the wave, registers i, i + 1 -- lies in one lane: the pooled map is written from the
+    // same registers (the pieces of a value are a monotone function of the value, so max-then-split equals the pooled split map).
     const long out_plane = (long)p.outH * p.outW * p.cout;
+    int re = r, he = h;
+    asm volatile("" : "+v"(re), "+v"(he));      // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
+    const bool odd = re & 1;
+    const unsigned perm_sel = odd ? 0x03020706u : 0x05040100u;       // v_perm_b32 selector, see store_pair
+    auto swap_lanes = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
+    // Values a (pixel xa) and b (pixel xa + 1) of this lane's channel.  v_cvt_pk_bf16_f32 rounds both to bf16 (nearest even) into
+    // one word (a low, b high); the remainder a - bf16(a) is exact in float32 and gives the next piece.  The word is traded with the
+    // neighbouring lane and one byte permute builds what this lane stores: even lanes pixel xa, channels (r, r + 1) = (own a,
+    // neighbour's a); odd lanes pixel xa + 1, channels (r - 1, r) = (neighbour's b, own b).
+    auto store_pair = [&](uint16_t *row_base, long plane_stride, long px_stride, float a, float b) {
+        uint16_t *o = row_base + (odd ? px_stride - 1 : 0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            bf16x2 hv;
+            hv[0] = (__bf16)a;
+            hv[1] = (__bf16)b;
+            const unsigned mine = __builtin_bit_cast(unsigned, hv);
+            if (pl + 1 < NPL) {
+                a -= __uint_as_float(mine << 16);
+                b -= __uint_as_float(mine & 0xffff0000u);
+            }
+            const unsigned theirs = swap_lanes(mine);
+            *reinterpret_cast<unsigned *>(o + pl * plane_stride) = __builtin_amdgcn_perm(theirs, mine, perm_sel);
+        }
+    };
+    const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int co = nblk * UC_BN + n * 32 + r;
+        const int co = nblk * UC_BN + n * 32 + re;
         const float b = p.bias[co];
         const float sc = p.scale ? p.scale[co] : 1.f, sh = p.scale ? p.shift[co] : 0.f;
 #pragma unroll
@@ -212,17 +242,25 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
             uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + p.ox) * p.cout + co;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int x = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 float v = acc[m][n][i] + b;
                 if (p.scale) { v = v > 0.f ? v : 0.f; v = v * sc + sh; }
-                uint16_t *o = orow + (long)(x * p.sx) * p.cout;
-                float rest = v;
+                acc[m][n][i] = v;
+            }
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    const unsigned hb = bf16_rne_bits(rest);
-                    o[pl * out_plane] = (uint16_t)hb;
-                    rest -= bf16_bits_to_f32(hb);
-                }
+            for (int i = 0; i < 16; i += 2) {
+                const int x = tx0 + (i & 3) + 8 * (i >> 2) + 4 * he;
+                store_pair(orow + (long)(x * p.sx) * p.cout, out_plane, (long)p.sx * p.cout, acc[m][n][i], acc[m][n][i + 1]);
+            }
+        }
+        if (p.pool_out) {
+            const int yo = ty0 / 2 + wave;
+            uint16_t *prow = p.pool_out + ((long)yo * (p.outW / 2)) * p.cout + co;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {      // registers i .. i + 3: pixels x .. x + 3 -> pooled pixels x / 2, x / 2 + 1
+                const int xo = (tx0 + 8 * (i >> 2) + 4 * he) / 2;
+                const float q0 = fmaxf(fmaxf(acc[0][n][i], acc[0][n][i + 1]), fmaxf(acc[1][n][i], acc[1][n][i + 1]));
+                const float q1 = fmaxf(fmaxf(acc[0][n][i + 2], acc[0][n][i + 3]), fmaxf(acc[1][n][i + 2], acc[1][n][i + 3]));
+                store_pair(prow + (long)xo * p.cout, pool_plane, (long)p.cout, q0, q1);
             }
         }
     }

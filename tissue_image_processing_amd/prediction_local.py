@@ -96,7 +96,8 @@ class _ConvDesc(ctypes.Structure):
                 ("w", ctypes.c_int), ("planes", ctypes.c_int), ("weights", ctypes.c_void_p), ("ntaps", ctypes.c_int),
                 ("dy", ctypes.c_int * 9), ("dx", ctypes.c_int * 9), ("cout", ctypes.c_int), ("bias", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_h", ctypes.c_int),
-                ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int)]
+                ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int),
+                ("pool_out", ctypes.c_void_p)]
 
 
 _FILTERS = (128, 256, 512)
@@ -314,7 +315,7 @@ class _UNet(object):
         def buf(h, w, c):
             return torch.empty((planes, h, w, c), dtype=torch.bfloat16, device=x.device)
 
-        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None):
+        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None):
             wp, dy, dx = hw[name]
             cout = wp.shape[2] * 128
             d = _ConvDesc()
@@ -332,11 +333,12 @@ class _UNet(object):
             if out is None:
                 out, oh, ow = buf(h, w, cout), h, w
             d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = out.data_ptr(), oh, ow, sy, sx, oy, ox
+            d.pool_out = pooled.data_ptr() if pooled is not None else None
             timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout, len(dy)), 2.0 * h * w * len(dy) * (d.c0 + d.c1) * cout,
                   lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream)))
             return out
 
-        def double(blk, src, skip, h, w, first=False):
+        def double(blk, src, skip, h, w, first=False, pooled=None):
             if first:
                 a = buf(h, w, 128)
                 timed("first %dx%d 2->128" % (h, w), 2.0 * h * w * 18 * 128,
@@ -344,7 +346,7 @@ class _UNet(object):
                                                                      D(hw["f:d0.b1.t"]), D(a), planes, stream)))
             else:
                 a = conv(blk + ".c1", src, skip, h, w, blk + ".b1")
-            return conv(blk + ".c2", a, None, h, w, blk + ".b2")
+            return conv(blk + ".c2", a, None, h, w, blk + ".b2", pooled=pooled)
 
         def pool(t, h, w):
             o = buf(h // 2, w // 2, t.shape[3])
@@ -357,9 +359,10 @@ class _UNet(object):
             h, w = H, W
             cur = None
             for i in range(3):
-                f = double("d%d" % i, cur, None, h, w, first=(i == 0))
+                nxt = buf(h // 2, w // 2, _FILTERS[i])           # MaxPool2D(2) comes out of the second convolution's epilogue
+                f = double("d%d" % i, cur, None, h, w, first=(i == 0), pooled=nxt)
                 skips.append(f)
-                cur = pool(f, h, w)
+                cur = nxt
                 h, w = h // 2, w // 2
             cur = double("mid", cur, None, h, w)
             for i in range(3):

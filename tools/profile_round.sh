@@ -1,33 +1,35 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence for profiles/ into gpurun_out/prof/.
-#   classical leg: kernel stats with one frame in flight and with the default command (which also times the U-Net leg),
+#   classical leg: kernel stats with one frame in flight; the default command (headline = U-Net leg + classical leg),
 #   FETCH_SIZE / WRITE_SIZE in separate passes; U-Net leg: kernel stats and an MFMA-busy counter pass.
 set -o pipefail
-tag=${1:-r02x}
+tag=${1:-r03x}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# heartbeat: a profiled run (MIOpen's solver search under the tracer) can be silent for minutes, and a silent command is
+# heartbeat: a profiled run can be silent for minutes (the tracer buffers everything), and a silent command is
 # taken for a hung one
 ( while true; do date +%T >> $out/heartbeat.txt; sleep 45; done ) &
 hb=$!
 trap "kill $hb 2>/dev/null" EXIT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/s1 -o s1 -- python3 bench.py --inflight 1 --no-cpu-baseline --no-unet-leg > $out/${tag}_bench_inflight1_profiled.json 2> $out/s1.err || exit 1
-echo "stats inflight 1 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -o s3 -- python3 bench.py --no-cpu-baseline --unet-steps 3 > $out/${tag}_bench_default_profiled.json 2> $out/s3.err || exit 1
+# classical leg, one frame in flight: per-kernel durations that must agree with bench.py's HIP-event figures
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/s1 -o s1 -- python3 bench.py --workload classical --inflight 1 --no-cpu-baseline --no-secondary-leg --no-pcie-leg > $out/${tag}_bench_classical_inflight1_profiled.json 2> $out/s1.err || exit 1
+echo "stats classical inflight 1 done"
+# the default command (headline = U-Net leg, classical leg secondary), shortened
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/s3 -o s3 -- python3 bench.py --no-cpu-baseline --steps 6 --secondary-steps 32 > $out/${tag}_bench_default_profiled.json 2> $out/s3.err || exit 1
 echo "stats default done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-unet-leg > $out/pf.json 2> $out/pf.err || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --workload classical --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-secondary-leg --no-pcie-leg > $out/pf.json 2> $out/pf.err || exit 1
 echo "pmc fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-unet-leg > $out/pw.json 2> $out/pw.err || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --workload classical --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-secondary-leg --no-pcie-leg > $out/pw.json 2> $out/pw.err || exit 1
 echo "pmc write done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/su -o su -- python3 bench.py --workload unet --steps 3 --warmup 2 --no-cpu-baseline > $out/${tag}_bench_unet_profiled.json 2> $out/su.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/su -o su -- python3 bench.py --workload unet --steps 6 --warmup 3 --no-cpu-baseline --no-secondary-leg > $out/${tag}_bench_unet_profiled.json 2> $out/su.err || exit 1
 echo "stats unet done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pm -o pm -- python3 bench.py --workload unet --steps 1 --warmup 1 --no-cpu-baseline > $out/pm.json 2> $out/pm.err || exit 1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pm -o pm -- python3 bench.py --workload unet --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-secondary-leg --no-pcie-leg > $out/pm.json 2> $out/pm.err || exit 1
 echo "pmc mfma done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/ps -o ps -- python3 bench.py --workload projection --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/ps.json 2> $out/ps.err || exit 1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/ps -o ps -- python3 bench.py --workload projection --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-pcie-leg > $out/ps.json 2> $out/ps.err || exit 1
 echo "pmc mfma (score passes) done"
 cp $(find $out/s1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_inflight1.csv
-cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_default_inflight4.csv
+cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_default.csv
 cp $(find $out/su -name "*kernel_stats.csv" | head -1) $out/${tag}_unet_kernel_stats.csv
 f=$(find $out/pf -name "*counter_collection.csv" | head -1); w=$(find $out/pw -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $f $w $out/${tag}_pmc_traffic.json
