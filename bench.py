@@ -270,7 +270,8 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, dist if world > 1 else None,
-                                    torch.device("cuda", local_rank) if world > 1 else "cpu", estimate_drift=True)
+                                    torch.device("cuda", local_rank) if world > 1 else "cpu", estimate_drift=True,
+                                    block_frames=max(1, args.inflight))     # rounds: the exchange of one overlaps the next one's kernels
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -25,7 +25,8 @@ def main():
     tabs, ids = movie.process_movie(T, lambda t: stacks[t], backend, rank, world, d, "cpu", drifts)
     # the same movie with the drift ESTIMATED inside the sharded driver (planes exchanged between the ranks)
     backend2 = movie.GpuFrameBackend(2, Z, Y, X, device=0, keep_planes=True, inflight=2)   # two frames in flight per process
-    tabs_e, ids_e = movie.process_movie(T, lambda t: stacks[t], backend2, rank, world, d, "cpu", estimate_drift=True)
+    tabs_e, ids_e = movie.process_movie(T, lambda t: stacks[t], backend2, rank, world, d, "cpu", estimate_drift=True,
+                                        block_frames=1)      # rounds of one frame per rank: compute of the next round overlaps the exchange
     if rank == 0:
         np.savez(out_path, n=T, **{"ids_%d" % t: ids[t] for t in range(T)}, **{"area_%d" % t: tabs[t]["area"] for t in range(T)},
                  **{"eids_%d" % t: ids_e[t] for t in range(T)}, est=np.array([tb["drift"] for tb in tabs_e]))

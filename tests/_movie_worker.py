@@ -68,14 +68,16 @@ def main():
     import torch.distributed as dist
     from tissue_image_processing_amd import movie
     out_path, n_rep = sys.argv[1], int(sys.argv[2])
+    n_keep = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # > 0: only the first n_keep frames (uneven shards, T < world)
+    block = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None   # frames per rank and round
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if n_rep == 0:     # the drift-estimating variant (drifts are NOT given), both stitchers
-        frames = drifting_movie()
+        frames = drifting_movie(n_frames=n_keep or 5)
         tabs, ids = movie.process_movie(len(frames), lambda t: frames[t], OracleBackend(), rank, world, dist, "cpu",
-                                        estimate_drift=True)
+                                        estimate_drift=True, block_frames=block)
         tabs2, ids2 = movie.process_movie(len(frames), lambda t: frames[t], OracleBackend(), rank, world, dist, "cpu",
-                                          estimate_drift=True, stitcher="linker")
+                                          estimate_drift=True, stitcher="linker", block_frames=block)
         if rank == 0:
             np.savez(out_path, n=len(frames), drifts=np.array([tb["drift"] for tb in tabs]),
                      **{"ids_%d" % t: ids[t] for t in range(len(frames))},
@@ -86,9 +88,12 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "tracking.npz"))
     labs = list(g["labels"])
     frames = (labs + labs[::-1]) * n_rep          # a longer movie out of the golden frames
+    if n_keep:
+        frames = frames[:n_keep]
     drifts = np.zeros((len(frames), 2))
     drifts[1:] = (0.5, -0.3)
-    tabs, ids = movie.process_movie(len(frames), lambda t: frames[t], OracleBackend(), rank, world, dist, "cpu", drifts)
+    tabs, ids = movie.process_movie(len(frames), lambda t: frames[t], OracleBackend(), rank, world, dist, "cpu", drifts,
+                                    block_frames=block)
     if rank == 0:
         np.savez(out_path, n=len(frames), **{"ids_%d" % t: ids[t] for t in range(len(frames))})
     dist.barrier()

@@ -19,13 +19,13 @@ def _free_port():
     return p
 
 
-def _run(world, out, n_rep=1):
+def _run(world, out, n_rep=1, n_keep=0, block=0):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_movie_worker.py"), out, str(n_rep)],
-                                      env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_movie_worker.py"), out, str(n_rep), str(n_keep),
+                                       str(block)], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
 
@@ -82,3 +82,32 @@ def test_world2_estimates_drift_and_stitches(tmp_path):
         np.testing.assert_array_equal(a["lids_%d" % t], b["lids_%d" % t])
         np.testing.assert_array_equal(a["ids_%d" % t], want[t])
         np.testing.assert_array_equal(a["lids_%d" % t], a["lids_0"])
+
+
+@pytest.mark.parametrize("n_keep,block", [(7, 1), (7, 2), (1, 1), (3, 0)])
+def test_world4_uneven_shards_and_rounds(tmp_path, n_keep, block):
+    """world 4 with T not a multiple of the world size (7 frames: shards of 2, 2, 2, 1), with FEWER frames than ranks (3, and
+    the one-frame movie), worked off in rounds of 1 or 2 frames per rank (compute of round k+1 overlaps the exchange of round
+    k; ranks without a frame in a round join the collectives with empty payloads): identical ids to the one-process,
+    one-round run."""
+    out1, out4 = str(tmp_path / "w1.npz"), str(tmp_path / "w4.npz")
+    _run(1, out1, n_rep=2, n_keep=n_keep)
+    _run(4, out4, n_rep=2, n_keep=n_keep, block=block)
+    a, b = np.load(out1), np.load(out4)
+    assert int(a["n"]) == int(b["n"]) == n_keep
+    for t in range(n_keep):
+        np.testing.assert_array_equal(a["ids_%d" % t], b["ids_%d" % t])
+
+
+def test_world4_estimated_drift_across_round_borders(tmp_path):
+    """Drift estimation with rounds of one frame per rank on 4 ranks and 6 frames: rank 0's frame 4 needs frame 3's plane,
+    which rank 3 sends a round earlier -- held until frame 4 is computed.  Same drifts and ids as one process."""
+    out1, out4 = str(tmp_path / "d1.npz"), str(tmp_path / "d4.npz")
+    _run(1, out1, n_rep=0, n_keep=6)
+    _run(4, out4, n_rep=0, n_keep=6, block=1)
+    a, b = np.load(out1), np.load(out4)
+    assert int(a["n"]) == int(b["n"]) == 6
+    np.testing.assert_array_equal(a["drifts"], b["drifts"])
+    for t in range(6):
+        np.testing.assert_array_equal(a["ids_%d" % t], b["ids_%d" % t])
+        np.testing.assert_array_equal(a["lids_%d" % t], b["lids_%d" % t])

@@ -210,28 +210,27 @@ def propagate_ids(tables, lookups):
     return out
 
 
-def exchange_planes(n_frames, mine, backend, rank, world, dist):
-    """Every owner of a frame t >= 1 gets frame t-1's plane: rank r sends its planes to rank (r+1) % world and receives
-    from (r-1) % world, all pairs at once (grouped isend/irecv: over RCCL each pair has its own xGMI link, no ring)."""
+def exchange_planes(n_frames, sends, recvs, backend, rank, world, dist):
+    """Plane hand-off for drift estimation: frame t's owner needs frame t-1's reference-channel plane, which lives on rank
+    (t-1) % world.  `sends`: this rank's frames whose planes go to rank (rank+1) % world; `recvs`: frames t-1 owned by rank
+    (rank-1) % world whose planes arrive here -- both in increasing order on either side of a pair, all pairs at once
+    (grouped isend/irecv: over RCCL each pair has its own xGMI link, no ring).  Returns {t: plane of frame t-1}."""
     prev = {}
     if world == 1:
-        for t in mine:
-            if t >= 1:
-                prev[t] = backend.plane(t - 1)
+        for t in recvs:
+            prev[t + 1] = backend.plane(t)
         return prev
     # gloo (the CPU test harness) moves host tensors only: device planes are staged through the host there; RCCL sends
     # the device planes as they are
     staged = dist.get_backend() == "gloo"
     ops, landing = [], {}
-    for t in mine:                                   # increasing t on both sides: matching order per pair
-        if t + 1 < n_frames:
-            src = backend.plane(t)
-            ops.append(dist.P2POp(dist.isend, src.cpu() if staged and src.is_cuda else src, (rank + 1) % world))
-    for t in mine:
-        if t >= 1:
-            prev[t] = backend.empty_plane()
-            landing[t] = prev[t].cpu() if staged and prev[t].is_cuda else prev[t]
-            ops.append(dist.P2POp(dist.irecv, landing[t], (rank - 1) % world))
+    for t in sends:
+        src = backend.plane(t)
+        ops.append(dist.P2POp(dist.isend, src.cpu() if staged and src.is_cuda else src, (rank + 1) % world))
+    for t in recvs:
+        prev[t + 1] = backend.empty_plane()
+        landing[t + 1] = prev[t + 1].cpu() if staged and prev[t + 1].is_cuda else prev[t + 1]
+        ops.append(dist.P2POp(dist.irecv, landing[t + 1], (rank - 1) % world))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -260,82 +259,111 @@ def link_ids(tables, drifts):
 
 
 def process_movie(n_frames, frame_source, backend, rank=0, world=1, dist=None, device="cpu", drifts=None,
-                  estimate_drift=False, stitcher="lookup"):
+                  estimate_drift=False, stitcher="lookup", block_frames=None):
     """Runs the sharded pipeline.  frame_source(t) -> uint16 stack (or whatever backend.process_frame takes).
     Returns on rank 0: (tables per frame, track ids per frame); on other ranks (None, None).  tables[t]["drift"] holds
-    the (row, column) drift used between frames t-1 and t (estimated by frame t's owner when estimate_drift)."""
+    the (row, column) drift used between frames t-1 and t (estimated by frame t's owner when estimate_drift).
+
+    The movie is worked off in ROUNDS of `block_frames` frames per rank (round k = global frames [k B W, (k+1) B W)): while
+    the workers compute round k+1, this thread runs round k's exchange -- planes to the neighbour rank, drift, all-gather of
+    the centroid tables, owner-side look-ups, gather of the index arrays to rank 0 -- so the stitching traffic and the drift
+    correlations hide behind the next frames' kernels instead of forming a tail after the last frame.  Every rank runs the same
+    number of rounds (a rank without frames in a round takes part with empty payloads: the collectives stay matched), so any
+    n_frames works, including fewer frames than ranks.  block_frames=None: the whole shard in one round (no overlap)."""
+    import threading
+    if stitcher not in ("lookup", "linker"):
+        raise ValueError("stitcher must be 'lookup' or 'linker'")
     if drifts is None:
         drifts = np.zeros((n_frames, 2))
     drifts = np.array(drifts, dtype=np.float64)
-    mine = list(range(rank, n_frames, world))
-    if hasattr(backend, "process_frames"):
-        local = backend.process_frames(mine, frame_source)        # several frames in flight on this rank's GPU
-    else:
-        local = {t: backend.process_frame(t, frame_source(t)) for t in mine}
-    if estimate_drift:
-        prev = exchange_planes(n_frames, mine, backend, rank, world, dist)
+    per_round = (int(block_frames) if block_frames else max(1, -(-n_frames // world))) * world
+    n_rounds = max(1, -(-n_frames // per_round))
+    rounds = [[t for t in range(k * per_round, min(n_frames, (k + 1) * per_round)) if t % world == rank] for k in range(n_rounds)]
+
+    def compute(frames, out):
+        try:
+            if not frames:
+                return
+            if hasattr(backend, "process_frames"):
+                out.update(backend.process_frames(frames, frame_source))        # several frames in flight on this rank's GPU
+            else:
+                out.update({t: backend.process_frame(t, frame_source(t)) for t in frames})
+        except BaseException as e:
+            out["error"] = e
+
+    tables, lookups, held_planes = {}, {}, {}
+    results = [dict() for _ in range(n_rounds)]
+    worker = threading.Thread(target=compute, args=(rounds[0], results[0]))
+    worker.start()
+    for k in range(n_rounds):
+        worker.join()
+        if "error" in results[k]:
+            raise results[k]["error"]
+        local, mine = results[k], rounds[k]
+        if k + 1 < n_rounds:                       # the next round computes while this one is exchanged
+            worker = threading.Thread(target=compute, args=(rounds[k + 1], results[k + 1]))
+            worker.start()
+        lo, hi = k * per_round, min(n_frames, (k + 1) * per_round)
+        if estimate_drift:
+            sends = [t for t in mine if t + 1 < n_frames]
+            recvs = [t for t in range(lo, hi) if t % world == (rank - 1) % world and t + 1 < n_frames]
+            held_planes.update(exchange_planes(n_frames, sends, recvs, backend, rank, world, dist))
+            for t in mine:
+                if t >= 1:
+                    drifts[t] = backend.drift(t, held_planes.pop(t))
         for t in mine:
-            if t >= 1:
-                drifts[t] = backend.drift(t, prev.pop(t))
-    for t in mine:
-        local[t]["drift"] = drifts[t].copy()
-    # 1. centroid tables everywhere
-    if world > 1:
-        payload = []
-        for t in mine:
-            tb = local[t]
-            payload += [np.array([t, tb["area"].size, tb["drift"][0], tb["drift"][1]], np.float64),
-                        tb["area"].astype(np.float64), tb["cy"], tb["cx"]]
-        gathered = _all_gather_arrays(payload, dist, world, device)
-        tables = {}
-        for flat in gathered:
-            pos = 0
-            while pos < flat.size:
-                t, n = int(flat[pos]), int(flat[pos + 1])
-                drift_t = flat[pos + 2:pos + 4].copy()
-                pos += 4
-                tables[t] = dict(area=flat[pos:pos + n].astype(np.int64), cy=flat[pos + n:pos + 2 * n],
-                                 cx=flat[pos + 2 * n:pos + 3 * n], drift=drift_t)
-                pos += 3 * n
-    else:
-        tables = local
-    if stitcher == "linker":
-        if rank != 0:
-            return None, None
-        tabs = [tables[t] for t in range(n_frames)]
-        return tabs, link_ids(tabs, [tb["drift"] for tb in tabs])
-    if stitcher != "lookup":
-        raise ValueError("stitcher must be 'lookup' or 'linker'")
-    # 2. owners look previous centroids up in their resident label maps
-    my_lookups = {}
-    for t in mine:
-        if t == 0:
+            local[t]["drift"] = drifts[t].copy()
+        # 1. centroid tables of the round everywhere
+        if world > 1:
+            payload = []
+            for t in mine:
+                tb = local[t]
+                payload += [np.array([t, tb["area"].size, tb["drift"][0], tb["drift"][1]], np.float64),
+                            tb["area"].astype(np.float64), tb["cy"], tb["cx"]]
+            for flat in _all_gather_arrays(payload, dist, world, device):
+                pos = 0
+                while pos < flat.size:
+                    t, n = int(flat[pos]), int(flat[pos + 1])
+                    drift_t = flat[pos + 2:pos + 4].copy()
+                    pos += 4
+                    tables[t] = dict(area=flat[pos:pos + n].astype(np.int64), cy=flat[pos + n:pos + 2 * n],
+                                     cx=flat[pos + 2 * n:pos + 3 * n], drift=drift_t)
+                    pos += 3 * n
+        else:
+            tables.update({t: local[t] for t in mine})
+        if stitcher == "linker":
             continue
-        prev = tables[t - 1]
-        cy = prev["cy"] - drifts[t][0]
-        cx = prev["cx"] - drifts[t][1]
-        qy, qx = np.round(cy).astype(np.int64), np.round(cx).astype(np.int64)
-        res = backend.lookup(t, qy, qx)
-        res = np.where(prev["area"] > 0, res, -1)   # absent rows never match (empty_cell / zero-area rows)
-        my_lookups[t] = res
-    # 3. gather to rank 0
-    if world > 1:
-        flat = []
-        for t, r in my_lookups.items():
-            flat += [np.array([t, r.size], np.int64), r.astype(np.int64)]
-        flat = np.concatenate(flat) if flat else np.zeros(0, np.int64)
-        parts = _gather_to_root(flat, dist, rank, world, device)
-        if rank != 0:
-            return None, None
-        lookups = {}
-        for p in parts:
-            pos = 0
-            while pos < p.size:
-                t, n = int(p[pos]), int(p[pos + 1])
-                lookups[t] = p[pos + 2:pos + 2 + n]
-                pos += 2 + n
-    else:
-        lookups = my_lookups
+        # 2. owners look the previous frame's centroids up in their resident label maps
+        my_lookups = {}
+        for t in mine:
+            if t == 0:
+                continue
+            prev = tables[t - 1]
+            cy = prev["cy"] - tables[t]["drift"][0]
+            cx = prev["cx"] - tables[t]["drift"][1]
+            qy, qx = np.round(cy).astype(np.int64), np.round(cx).astype(np.int64)
+            res = backend.lookup(t, qy, qx)
+            my_lookups[t] = np.where(prev["area"] > 0, res, -1)   # absent rows never match (empty_cell / zero-area rows)
+        # 3. gather to rank 0
+        if world > 1:
+            flat = []
+            for t, r in my_lookups.items():
+                flat += [np.array([t, r.size], np.int64), r.astype(np.int64)]
+            flat = np.concatenate(flat) if flat else np.zeros(0, np.int64)
+            parts = _gather_to_root(flat, dist, rank, world, device)
+            if rank == 0:
+                for p in parts:
+                    pos = 0
+                    while pos < p.size:
+                        t, n = int(p[pos]), int(p[pos + 1])
+                        lookups[t] = p[pos + 2:pos + 2 + n]
+                        pos += 2 + n
+        else:
+            lookups.update(my_lookups)
+    if rank != 0:
+        return None, None
     tabs = [tables[t] for t in range(n_frames)]
+    if stitcher == "linker":
+        return tabs, link_ids(tabs, [tb["drift"] for tb in tabs])
     ids = propagate_ids(tabs, [None] + [lookups[t] for t in range(1, n_frames)])
     return tabs, ids
