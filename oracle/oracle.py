@@ -166,6 +166,19 @@ def set_brightness(image, axes, metadata=None, method="bestFit", clearExtreamPre
     return adjusted
 
 
+def stretch_for_display(disp_img, min_percent, max_percent):
+    """gui.py:445-452 (display_frame): plane -> 255 * clip((plane - p_lo) / (p_hi - p_lo)), levels from np.percentile."""
+    img = np.asarray(disp_img)
+    lo, hi = percentile_linear(img, min_percent), percentile_linear(img, max_percent)
+    if hi == lo:
+        hi += 1
+    out = img - lo
+    np.putmask(out, out < 0, 0)
+    out = 255 * out / (hi - lo)
+    np.putmask(out, out > 255, 255)
+    return out
+
+
 def tiff_normalise(image, data_type):
     """The conversion save_tiff applies before writing (bim.py:183-186)."""
     if data_type and image.dtype != data_type and data_type in ("uint8", "uint16"):
@@ -310,6 +323,37 @@ def resize_linear(a, out_yx):
     return t.astype(np.float32)
 
 
+def resize_warp2d(a, out_yx):
+    """skimage.transform.resize(a.astype('float32'), (Y, X)) for a 2-D array (sp.py:64-65: the plane maps of build_manifold with
+    bin_size > 1).  2-D arrays take skimage's bilinear warp (_warps_cy, a binary): source coordinate scale * i + (scale / 2 -
+    1 / 2) evaluated in float32, corners floor / ceil with numpy 'reflect' borders (index -1 -> 1), (1 - dc) v00 + dc v01 for
+    top and bottom, (1 - dr) top + dr bottom in double, float32 out.  Agrees with skimage to ~1e-6 (upstream's affine matrix
+    comes out of a least-squares estimate); np.round of it equals the reference's on every golden, .5 ties included."""
+    a = np.asarray(a, np.float32)
+    Y, X = out_yx
+
+    def axis(n_in, n_out):
+        s = np.float64(n_in) / np.float64(n_out)
+        f = np.float32(s) * np.arange(n_out, dtype=np.float32) + np.float32(0.5 * s - 0.5)
+        lo, hi = np.floor(f).astype(np.int64), np.ceil(f).astype(np.int64)
+        d = (f - lo.astype(np.float32)).astype(np.float64)
+
+        def mirror(c):
+            if n_in == 1:
+                return np.zeros_like(c)
+            p = 2 * (n_in - 1)
+            c = np.abs(c) % p
+            return np.where(c > n_in - 1, p - c, c)
+        return mirror(lo), mirror(hi), d
+    y0, y1, dr = axis(a.shape[0], Y)
+    x0, x1, dc = axis(a.shape[1], X)
+    v = a.astype(np.float64)
+    dr, dc = dr[:, None], dc[None, :]
+    top = (1.0 - dc) * v[y0][:, x0] + dc * v[y0][:, x1]
+    bot = (1.0 - dc) * v[y1][:, x0] + dc * v[y1][:, x1]
+    return ((1.0 - dr) * top + dr * bot).astype(np.float32)
+
+
 def build_continues_manifold(score):
     """sp.py:87-165: the spiral z-map (C restatement orc_build_manifold_f32; int64 like upstream's astype(int))."""
     s = np.ascontiguousarray(score, dtype=np.float32)
@@ -323,10 +367,8 @@ def build_continues_manifold(score):
 def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, max_z=0,
                                   method="max_averages", bin_size=1, airyscan=True, z_map=False,
                                   atoh_shift=0, build_manifold=False, clip_from=None):
-    """sp.py:17-85 (build_manifold with bin_size 1 only).  clip_from (not in the reference): the array whose non-zero 95th percentile
+    """sp.py:17-85.  clip_from (not in the reference): the array whose non-zero 95th percentile
     clips the reference channel instead of the channel's own -- a spatial tile passes the whole frame's channel."""
-    if build_manifold and bin_size > 1:
-        raise NotImplementedError("oracle: build_manifold with bin_size 1")
     if axes.find("T") >= 0:
         time_point = time_point.reshape(time_point.shape[1:])
         image, _ = put_channel_axis_first(time_point, axes[1:])
@@ -361,11 +403,15 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
             score = block_mean(blur_image(atoh, (0.5, 30, 30)), bin_size) * block_var(ch, bin_size)
         else:
             raise TypeError("exceptions must derive from BaseException")   # `raise "No such method"` (sp.py:53)
-        score = resize_linear(score, (y_size, x_size))
+        if not build_manifold:
+            score = resize_linear(score, (y_size, x_size))
     else:
         score = blur_image(ch, (0.5, 30, 30))
     chosen_z = build_continues_manifold(score) if build_manifold else min_z + np.argmax(score, axis=0)   # (sp.py:56-61)
     chosen_z_atoh = np.copy(chosen_z) if atoh_shift == 0 else np.clip(chosen_z + atoh_shift, 0, score.shape[0])
+    if chosen_z.shape != (y_size, x_size):          # the spiral ran on the binned score (sp.py:63-65)
+        chosen_z = np.round(resize_warp2d(chosen_z.astype("float32"), (y_size, x_size))).astype("int")
+        chosen_z_atoh = np.round(resize_warp2d(chosen_z_atoh.astype("float32"), (y_size, x_size))).astype("int")
     mask = np.zeros((z_size, y_size * x_size), np.float32)
     mask_atoh = np.zeros((z_size, y_size * x_size), np.float32)
     mask[chosen_z.ravel(), np.arange(x_size * y_size)] = 1

@@ -202,6 +202,17 @@ def test_cell_tables_with_more_labels_than_tile_slots():
     assert set(map(tuple, np.asarray(gp).tolist())) == set(map(tuple, np.asarray(wp).tolist()))
 
 
+def test_display_stretch_golden(env, golden):
+    """gui.py:445-452: the composite's level stretch with its two percentiles from the device radix select."""
+    bim, _, _, _ = env
+    g = golden("display_stretch")
+    for k in range(int(g["n"])):
+        lo, hi = g["d%d_levels" % k]
+        out = bim.stretch_for_display(g["d%d_in" % k], lo, hi)
+        assert out.dtype == np.float64
+        np.testing.assert_array_equal(out, g["d%d_out" % k])
+
+
 def test_display_ops_golden(env, golden, tmp_path):
     """band_pass_filter, set_brightness (device order statistics + scipy's weighting), save_tiff's
     normalisation and the self-contained TIFF writer, against the reference's own outputs."""

@@ -37,8 +37,28 @@ def test_projection_with_manifold_golden(g, monkeypatch, golden_taps):
                                                   build_manifold=True, atoh_shift=-1)
     np.testing.assert_array_equal(zmap, g["p2_zmap"])        # (min_z is NOT added on this path, as upstream)
     np.testing.assert_array_equal(proj, g["p2_proj"])
-    with pytest.raises(NotImplementedError):
-        sp.time_point_surface_projection(g["p_stack"], "CZYX", 0, airyscan=False, build_manifold=True, bin_size=4)
+
+
+def test_projection_with_manifold_and_bin_size_golden(monkeypatch, golden_taps):
+    """build_manifold with bin_size > 1 (sp.py:56-65): goldens from the reference's own function (spiral on the binned score,
+    plane maps through skimage's 2-D resize, np.round), all three scoring methods and an atoh shift; plus the oracle on a
+    ragged shape."""
+    from oracle import oracle as orc
+    from tissue_image_processing_amd import surface_projection as sp, synthetic
+    from gpu_util import taps_patch
+    taps_patch(monkeypatch, golden_taps)
+    gb = np.load(os.path.join(ROOT, "tests", "golden", "manifold_binned.npz"))
+    for name, kw in (("avg4", dict(bin_size=4, method="max_averages")), ("std4", dict(bin_size=4, method="max_std")),
+                     ("multi10", dict(bin_size=10, method="multi_channel")), ("avg5_shift", dict(bin_size=5, method="max_averages", atoh_shift=1))):
+        proj, zmap = sp.time_point_surface_projection(gb["p_stack"][None], "TCZYX", 0, airyscan=False, z_map=True, build_manifold=True, **kw)
+        np.testing.assert_array_equal(zmap, gb["p_%s_zmap" % name], err_msg=name)
+        np.testing.assert_array_equal(proj, gb["p_%s_proj" % name], err_msg=name)
+    st = synthetic.make_stack(9, 75, 131, seed=530)
+    for kw in (dict(bin_size=7, method="max_std"), dict(bin_size=3, method="max_averages", atoh_shift=-1)):
+        proj, zmap = sp.time_point_surface_projection(st, "CZYX", 0, airyscan=False, z_map=True, build_manifold=True, **kw)
+        p_ref, z_ref = orc.time_point_surface_projection(st, "CZYX", 0, airyscan=False, z_map=True, build_manifold=True, **kw)
+        np.testing.assert_array_equal(zmap, z_ref)
+        np.testing.assert_array_equal(proj, p_ref)
 
 
 @pytest.mark.parametrize("shape,start", [((30, 300, 340), None), ((50, 90, 1500), (7, 40, 2)), ((9, 2600, 37), (3, 2599, 36)),

@@ -281,3 +281,33 @@ def test_manifold_golden(golden):
                                              build_manifold=True, atoh_shift=-1)
     np.testing.assert_array_equal(z, g["p2_zmap"])
     np.testing.assert_array_equal(p, g["p2_proj"])
+
+
+_BINNED_MANIFOLD = (("avg4", dict(bin_size=4, method="max_averages")), ("std4", dict(bin_size=4, method="max_std")),
+                    ("multi10", dict(bin_size=10, method="multi_channel")), ("avg5_shift", dict(bin_size=5, method="max_averages", atoh_shift=1)))
+
+
+def test_manifold_with_bin_size_golden(golden):
+    """build_manifold together with bin_size > 1 (sp.py:56-65): the spiral on the binned score, the plane maps resized to the
+    frame by skimage's 2-D bilinear warp and rounded.  The restated warp agrees with skimage's float output to 1e-5 (its affine
+    matrix comes out of a least-squares estimate) and exactly for power-of-two factors; np.round of it -- what the reference
+    uses -- equals the reference on every case, exact .5 ties included; so do the whole projections."""
+    g = golden("manifold_binned")
+    for k in range(int(g["r_n"])):
+        got = orc.resize_warp2d(g["r%d_in" % k], g["r%d_out" % k].shape)
+        np.testing.assert_allclose(got, g["r%d_out" % k], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(np.round(got), np.round(g["r%d_out" % k]))
+    np.testing.assert_array_equal(orc.resize_warp2d(g["r0_in"], g["r0_out"].shape), g["r0_out"])
+    for name, kw in _BINNED_MANIFOLD:
+        p, z = orc.time_point_surface_projection(g["p_stack"][None], "TCZYX", 0, airyscan=False, z_map=True, build_manifold=True, **kw)
+        np.testing.assert_array_equal(z, g["p_%s_zmap" % name], err_msg=name)
+        np.testing.assert_array_equal(p, g["p_%s_proj" % name], err_msg=name)
+
+
+def test_display_stretch_golden(golden):
+    """The display stretch of gui.py:445-452 (levels from np.percentile, equal levels, 0 / 100): numpy statements evaluated by
+    the golden interpreter (gui.py itself needs PyQt5 and a window)."""
+    g = golden("display_stretch")
+    for k in range(int(g["n"])):
+        lo, hi = g["d%d_levels" % k]
+        np.testing.assert_array_equal(orc.stretch_for_display(g["d%d_in" % k], lo, hi), g["d%d_out" % k])

@@ -210,6 +210,24 @@ def set_brightness(image, axes, metadata={}, method='bestFit', clearExtreamPrece
     return adjusted, meta
 
 
+def stretch_for_display(disp_img, min_percent, max_percent):
+    """The display stretch of gui.py:445-452 / 468-475 (display_frame: the zo and atoh planes of the composite): both level
+    percentiles of the plane (np.percentile, linear), a maximum equal to the minimum is moved up by one, then
+    255 * max(plane - lo, 0) / (hi - lo) clipped at 255, in float64.  The two order statistics -- the only dense-array work --
+    come from the device radix select (tip_label_order_stats_f64); the arithmetic on them is numpy's."""
+    from . import _segmentation as seg
+    img = np.asarray(disp_img)
+    lo = seg.percentile_frame(img, float(min_percent))
+    hi = seg.percentile_frame(img, float(max_percent))
+    if hi == lo:
+        hi += 1
+    out = img - lo
+    np.putmask(out, out < 0, 0)
+    out = 255 * out / (hi - lo)
+    np.putmask(out, out > 255, 255)
+    return out
+
+
 def tiff_normalise(image, data_type=""):
     """The conversion save_tiff applies before writing (bim.py:183-186): images that are not already of the requested
     unsigned type are scaled so that their maximum becomes the type's maximum, and rounded."""

@@ -801,6 +801,51 @@ __global__ void __launch_bounds__(256) k_emit_zmaps(const int *__restrict__ best
     zsel_atoh[p] = ca;
 }
 
+// build_manifold with bin_size > 1 (sp.py:56-65): the (Yb, Xb) plane map of the binned score goes back to the frame through
+// skimage.transform.resize(order 1, mode 'reflect') -- for 2-D arrays the bilinear warp of _warps_cy: source coordinate
+// a * i + b (a = n_in / n_out, b = a / 2 - 1 / 2) evaluated in float32, corners floor / ceil with numpy 'reflect' (mirror
+// without the edge: index -1 -> 1), top = (1 - dc) v00 + dc v01, bottom likewise, (1 - dr) top + dr bottom in double, float32
+// result -- and np.round (half to even).  The float result agrees with skimage's to ~1e-6 (upstream's affine matrix comes out
+// of a least-squares estimate, LAPACK-dependent in the last bit); the rounded maps equal the reference's on every golden,
+// exact .5 ties included.  The atoh map is clip(plane + shift, 0, Z) BEFORE the resize, as upstream.
+__device__ __forceinline__ int mirror_index(int n, int c)
+{
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    c = (c < 0 ? -c : c) % p;
+    return c > n - 1 ? p - c : c;
+}
+__global__ void __launch_bounds__(256) k_resize_round_zmaps(const int *__restrict__ bz, int Yb, int Xb, int Y, int X, int Z, int atoh_shift,
+                                                            int32_t *__restrict__ zsel, int32_t *__restrict__ zsel_atoh,
+                                                            int64_t *__restrict__ zmap, int *__restrict__ err)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= X) return;
+    const double sy = (double)Yb / Y, sx = (double)Xb / X;
+    const float ar = (float)sy, br = (float)(0.5 * sy - 0.5), ac = (float)sx, bc = (float)(0.5 * sx - 0.5);
+    const float fr = ar * (float)y + br, fc = ac * (float)x + bc;
+    const int r0 = (int)floorf(fr), c0 = (int)floorf(fc), r1 = (int)ceilf(fr), c1 = (int)ceilf(fc);
+    const double dr = (double)(fr - (float)r0), dc = (double)(fc - (float)c0);
+    const int y0 = mirror_index(Yb, r0), y1 = mirror_index(Yb, r1), x0 = mirror_index(Xb, c0), x1 = mirror_index(Xb, c1);
+    int res[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        auto at = [&](int yy, int xx) -> double {
+            int v = bz[(long)yy * Xb + xx];
+            if (k == 1 && atoh_shift != 0) { v += atoh_shift; v = v < 0 ? 0 : (v > Z ? Z : v); }
+            return (double)v;
+        };
+        const double top = (1.0 - dc) * at(y0, x0) + dc * at(y0, x1);
+        const double bot = (1.0 - dc) * at(y1, x0) + dc * at(y1, x1);
+        res[k] = (int)rintf((float)((1.0 - dr) * top + dr * bot));      // np.round: half to even (default rounding mode)
+    }
+    const long p = (long)y * X + x;
+    if (zmap) zmap[p] = res[0];
+    if (res[0] >= Z || res[1] >= Z) atomicOr(err, 1);
+    zsel[p] = res[0] >= Z ? Z - 1 : res[0];
+    zsel_atoh[p] = res[1] >= Z ? Z - 1 : res[1];
+}
+
 // ---- P4': bin_size > 1 (sp.py:39-65) -------------------------------------------------------------------------------
 // skimage.measure.block_reduce(vol, (1, b, b), np.mean / np.var) in float32 with numpy's summation order: every row of
 // a block (b contiguous samples, zeros beyond the frame) goes through numpy's pairwise_sum -- a running sum below 8
@@ -953,7 +998,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
     const long P = (long)Y * X, V = (long)Zs * P;
     const bool manifold = (method & TIP_PROJECT_MANIFOLD) != 0;      // sp.py:56-57: the spiral z-map instead of the argmax
     method &= ~TIP_PROJECT_MANIFOLD;
-    if (manifold && (bin != 1 || hist_in)) return fail(TIP_ERR_UNSUPPORTED, "project: build_manifold takes bin_size 1, whole frames");
+    if (manifold && hist_in) return fail(TIP_ERR_UNSUPPORTED, "project: build_manifold takes whole frames");
     if (manifold && (V >= 0xffffffffL || Zs > 144)) return fail(TIP_ERR_UNSUPPORTED, "project: build_manifold: stack too large");
     Taps k05, k1, k2, k30;
     int rc;
@@ -1043,9 +1088,18 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
                 TIP_LAUNCH("mul_f32", k_mul_f32, dim3(cdiv(nb, 256)), dim3(256), 0, S1, (const float *)S2, nb);
             }
         }
+        if (manifold) {
+            // sp.py:56-57, 63-65: the spiral on the BINNED score, then the plane maps resized to the frame and rounded
+            int *bz = ws.get<int>((size_t)Yb * Xb);
+            if (!bz) return TIP_ERR_NOMEM;
+            if ((rc = manifold_dev((const float *)S1, Zs, Yb, Xb, bz, err))) return rc;
+            TIP_LAUNCH("resize_round_zmaps", k_resize_round_zmaps, dim3(cdiv(X, 256), Y), dim3(256), 0, (const int *)bz, Yb, Xb, Y, X, Zs,
+                       atoh_shift, zsel, zsel_a, zmap, err);
+        } else {
         TIP_LAUNCH("resize_argmax", k_resize_argmax, dim3(cdiv(X, 256), Y), dim3(256), 0, (const float *)S1, Zs, Yb, Xb, Y, X, bestz);
         TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
                    zsel_a, zmap, err);
+        }
     } else {
     // P4 + P5: (0.5, 30, 30) score and its argmax
     const bool certified = fast && Zs <= 64 && !manifold && !tuning().project_exact_score;
@@ -1173,7 +1227,6 @@ static int project_host(const uint16_t *czyx, int c, int z, int y, int x, int zl
 static int check_binned(int method, int bin)
 {
     if (method >= 0 && (method & TIP_PROJECT_MANIFOLD)) {
-        if (bin != 1) return fail(TIP_ERR_UNSUPPORTED, "projection: build_manifold with bin_size %d (bin_size 1 supported)", bin);
         method &= ~TIP_PROJECT_MANIFOLD;
     }
     if (method < 0 || method > 2) return fail(TIP_ERR_ARG, "projection: method %d (0 max_averages, 1 max_std, 2 multi_channel)", method);

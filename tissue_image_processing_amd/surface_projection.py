@@ -4,7 +4,7 @@ movie / large-image drivers around it (sp.py:168-316).
 Signature, defaults, return types and error behaviour follow the reference; the arithmetic runs in
 libtissue_hip.so (tip_project_u16 / tip_project_u16_binned).  Covered: bin_size == 1 (what every BASELINE config and
 movie_surface_projection's default use) and bin_size > 1 with methods 'max_averages', 'max_std', 'multi_channel'
-(sp.py:39-65), and build_manifold (the spiral of sp.py:87-165, as a scan of function tables on the device) with bin_size 1.
+(sp.py:39-65), and build_manifold (the spiral of sp.py:87-165, as a scan of function tables on the device), also on the binned score.
 """
 
 _METHODS = {"max_averages": 0, "max_std": 1, "multi_channel": 2}
@@ -22,8 +22,6 @@ def time_point_surface_projection(time_point, axes, reference_channel, min_z=0, 
                                   build_manifold=False):
     if bin_size > 1 and method not in ("max_averages", "max_std", "multi_channel"):
         raise TypeError("exceptions must derive from BaseException")  # sp.py:53 raises a str
-    if build_manifold and bin_size > 1:
-        raise NotImplementedError("MI355X path covers build_manifold with bin_size 1")
     if bin_size > 128:
         raise NotImplementedError("MI355X path covers bin_size <= 128")
     if axes.find("T") >= 0:

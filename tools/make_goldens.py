@@ -198,6 +198,34 @@ def gold_display_ops():
     save("display_ops", **out)
 
 
+def gold_display_stretch():
+    """The display stretch of gui.py:445-452 (display_frame).  gui.py needs PyQt5 and a live window, so the statements of
+    those lines are evaluated here with the golden interpreter's numpy on seeded planes (uint16 as the GUI holds them, and
+    float64; ordinary levels, equal levels, the 0 / 100 extremes)."""
+    rng = np.random.default_rng(43)
+    out = {}
+    planes = {"u16": rng.integers(50, 30000, (61, 83)).astype(np.uint16), "f64": rng.random((45, 52)) * 7000.0,
+              "flat": np.full((20, 30), 17, np.uint16)}
+    k = 0
+    for name, img in planes.items():
+        for lo_p, hi_p in ((1, 99), (0, 100), (30, 30), (12.5, 87.5)):
+            disp_img = img.T
+            min_level = np.percentile(disp_img, lo_p)
+            max_level = np.percentile(disp_img, hi_p)
+            if max_level == min_level:
+                max_level += 1
+            disp_img = disp_img - min_level
+            np.putmask(disp_img, disp_img < 0, 0)
+            disp_img = 255 * disp_img / (max_level - min_level)
+            np.putmask(disp_img, disp_img > 255, 255)
+            out["d%d_in" % k] = img.T.copy()
+            out["d%d_levels" % k] = np.array([lo_p, hi_p], np.float64)
+            out["d%d_out" % k] = disp_img
+            k += 1
+    out["n"] = np.array(k)
+    save("display_stretch", **out)
+
+
 def gold_rank_filters():
     rng = np.random.default_rng(21)
     lab = rng.integers(0, 40, (37, 53)).astype(np.int32)
@@ -754,6 +782,32 @@ def gold_manifold():
     save("manifold", **out)
 
 
+def gold_manifold_binned():
+    """time_point_surface_projection with build_manifold=True AND bin_size > 1 (sp.py:39-65): the spiral runs on the binned
+    score, then the (Yb, Xb) plane map is brought back to the frame with skimage's 2-D resize (order 1, mode 'reflect' ->
+    the bilinear warp of _warps_cy, shipped as a binary only) and np.round'ed.  The raw float output of that resize on integer
+    maps is stored as well, so the restatement of the warp's arithmetic is pinned directly (bin sizes whose sampling
+    fractions hit exact .5 ties with plane steps of 2 included)."""
+    from skimage.transform import resize
+    out = {}
+    rng = np.random.default_rng(777)
+    k = 0
+    for (yb, xb), (Y, X) in (((12, 14), (48, 56)), ((5, 6), (50, 60)), ((7, 5), (35, 25)), ((9, 13), (27, 39)), ((6, 7), (41, 45)), ((1, 9), (4, 36))):
+        zm = rng.integers(0, 9, (yb, xb)).astype(np.float32)
+        out["r%d_in" % k] = zm
+        out["r%d_out" % k] = resize(zm, (Y, X))
+        k += 1
+    out["r_n"] = np.array(k)
+    st = synthetic.make_stack(10, 48, 56, seed=520)
+    for name, kw in (("avg4", dict(bin_size=4, method="max_averages")), ("std4", dict(bin_size=4, method="max_std")),
+                     ("multi10", dict(bin_size=10, method="multi_channel")), ("avg5_shift", dict(bin_size=5, method="max_averages", atoh_shift=1))):
+        proj, zmap = sp.time_point_surface_projection(st[None].copy(), "TCZYX", 0, airyscan=False, z_map=True, build_manifold=True, **kw)
+        out["p_%s_proj" % name] = proj
+        out["p_%s_zmap" % name] = zmap
+    out["p_stack"] = st
+    save("manifold_binned", **out)
+
+
 def gold_local_drifts():
     """fix_one_frame_tracking_using_local_drifts (ti.py:2115-2246) with trackpy.link replaced by a deterministic stand-in
     that RECORDS the table it is given: pins (a) the drift-corrected centroids, i.e. the local-drift map of ti.py:2149-2175
@@ -931,6 +985,11 @@ def gold_misc_io():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:          # only the named sets (functions without arguments): make_goldens.py manifold_binned display_stretch
+        for name in sys.argv[1:]:
+            globals()["gold_" + name]()
+        print("done")
+        sys.exit(0)
     gold_weights()
     gold_gaussian()
     gold_percentile()
@@ -938,6 +997,7 @@ if __name__ == "__main__":
     gold_projection_binned()
     gold_rank_filters()
     gold_display_ops()
+    gold_display_stretch()
     gold_label()
     la, lb = gold_watershed(pa, pf)
     gold_cellinfo(la, lb)
@@ -949,6 +1009,7 @@ if __name__ == "__main__":
     gold_drivers()
     gold_seg()
     gold_manifold()
+    gold_manifold_binned()
     gold_local_drifts()
     gold_split_cell()
     gold_misc_io()
