@@ -64,6 +64,7 @@ struct Tuning {
     int project_generic = 0, project_unfused_preblur = 0, project_unfused_mask = 0;
     int project_exact_score = 0, project_debug = 0;
     int fast_cfg_y = -1, fast_cfg_x = -1;    // TIP_FAST_CFG=y,x
+    int unet_tile8 = 0;         // TIP_UNET_TILE8: the U-Net convolution's 8-row tiles everywhere (default: 16 rows where the grid allows)
 };
 const Tuning &tuning();
 

@@ -153,8 +153,8 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     if (!c.stream) return TIP_ERR_HIP;
     if (!d || !d->in0 || !d->weights || !d->bias || !d->out) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: null pointer");
     if (d->planes != 2 && d->planes != 3) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: planes must be 2 or 3");
-    if (d->h < UC_TH || d->w < UC_TW || d->h % UC_TH || d->w % UC_TW)
-        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: the grid %dx%d is not a multiple of the %dx%d pixel tile", d->h, d->w, UC_TH, UC_TW);
+    if (d->h < 8 || d->w < UC_TW || d->h % 8 || d->w % UC_TW)
+        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: the grid %dx%d is not a multiple of the 8x%d pixel tile", d->h, d->w, UC_TW);
     if (d->c0 < UC_KC || d->c0 % UC_KC || d->c1 < 0 || d->c1 % UC_KC || (d->c1 > 0 && !d->in1) || d->cout < UC_BN || d->cout % UC_BN)
         return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: channels (%d + %d -> %d) must be multiples of %d / %d", d->c0, d->c1, d->cout, UC_KC, UC_BN);
     if (d->ntaps < 1 || d->ntaps > 9 || d->sy < 1 || d->sx < 1 || d->oy < 0 || d->ox < 0 ||
@@ -179,19 +179,25 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     p.pool_out = (uint16_t *)d->pool_out;
     if (d->pool_out && (d->sy != 1 || d->sx != 1 || d->oy != 0 || d->ox != 0 || d->out_h != d->h || d->out_w != d->w))
         return fail(TIP_ERR_ARG, "tip_unet_conv_dev: pool_out needs the plain output mapping");
-    const dim3 grid((d->h / UC_TH) * (d->w / UC_TW), d->cout / UC_BN);
-    const int a_per = (d->planes * UC_HP * 2 + UC_THREADS - 1) / UC_THREADS;
-    const size_t lds = 2 * (size_t)a_per * UC_THREADS * 16 + (size_t)UC_NBBUF * d->planes * 256 * 16;
+    // 16-row tiles (one 512-thread workgroup per CU) where the grid allows: half the weight copies per MFMA, and LDS for five
+    // weight buffers (copies four steps ahead) when the stencil has >= 4 taps; two pieces only (LDS)
+    const int th = (d->planes == 2 && d->h % 16 == 0 && !tuning().unet_tile8) ? 16 : 8;
+    const int dist = (th == 16 && d->ntaps >= 4) ? 4 : 2;
+    const int threads = th * 32, hp = UC_HW * (th + 2);
+    const dim3 grid((d->h / th) * (d->w / UC_TW), d->cout / UC_BN);
+    const int a_per = (d->planes * hp * 2 + threads - 1) / threads;
+    const size_t lds = 2 * (size_t)a_per * threads * 16 + (size_t)(dist + 1) * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    if (d->planes == 2) {
-        static bool attr2 = false;
-        if (!attr2) { TIP_HIP(hipFuncSetAttribute((const void *)k_unet_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
-        hipLaunchKernelGGL(k_unet_conv<2>, grid, dim3(UC_THREADS), lds, s, p);
-    } else {
-        static bool attr3 = false;
-        if (!attr3) { TIP_HIP(hipFuncSetAttribute((const void *)k_unet_conv<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr3 = true; }
-        hipLaunchKernelGGL(k_unet_conv<3>, grid, dim3(UC_THREADS), lds, s, p);
-    }
+    static bool attr_set[4] = {false, false, false, false};
+    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? 2 : 1) : 0);
+    const void *fn = which == 3 ? (const void *)k_unet_conv<3, 8, 2>
+                   : which == 2 ? (const void *)k_unet_conv<2, 16, 4>
+                   : which == 1 ? (const void *)k_unet_conv<2, 16, 2> : (const void *)k_unet_conv<2, 8, 2>;
+    if (!attr_set[which]) { TIP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[which] = true; }
+    if (which == 3) hipLaunchKernelGGL((k_unet_conv<3, 8, 2>), grid, dim3(threads), lds, s, p);
+    else if (which == 2) hipLaunchKernelGGL((k_unet_conv<2, 16, 4>), grid, dim3(threads), lds, s, p);
+    else if (which == 1) hipLaunchKernelGGL((k_unet_conv<2, 16, 2>), grid, dim3(threads), lds, s, p);
+    else hipLaunchKernelGGL((k_unet_conv<2, 8, 2>), grid, dim3(threads), lds, s, p);
     return unet_launch_check("unet_conv");
 }
 

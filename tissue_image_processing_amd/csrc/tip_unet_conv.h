@@ -35,12 +35,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int UC_TH = 8, UC_TW = 32;          // pixel tile
+constexpr int UC_TW = 32;                     // pixel tile: TH rows (8 or 16: template parameter) x 32 columns
 constexpr int UC_BN = 128;                    // output channels per workgroup
 constexpr int UC_KC = 16;                     // input channels per chunk = K of one MFMA
-constexpr int UC_HW = UC_TW + 2, UC_HH = UC_TH + 2, UC_HP = UC_HW * UC_HH;   // halo tile: 34 x 10 = 340 pixels
-constexpr int UC_THREADS = 256;
-constexpr int UC_NBBUF = 3;                   // weight-tile buffers in LDS (copies run two steps ahead)
+constexpr int UC_HW = UC_TW + 2;               // halo tile: (TH + 2) rows of 34 pixels
 
 struct ConvParams {
     const uint16_t *in0, *in1;     // split-plane activations [plane][H][W][C]
@@ -78,26 +76,40 @@ __device__ __forceinline__ void uc_wait_barrier()
 // NPL = bf16 pieces per value (2 or 3).
 //
 // LDS image (one dynamic array; 16-byte slots):  two activation buffers of A_SLOTS slots -- slot (plane * 340 + pixel) * 2 + sh --
-// and UC_NBBUF weight buffers of NPL * 256 slots -- slot (plane * 128 + n) * 2 + sh.  A row (one pixel / one output channel) is
+// and D + 1 weight buffers of NPL * 256 slots -- slot (plane * 128 + n) * 2 + sh.  A row (one pixel / one output channel) is
 // 16 bf16 = 32 bytes = two slots; the two halves of row j are stored SWAPPED when bit 3 of j is set (sh = half ^ ((j >> 3) & 1)):
 // the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} of consecutive rows, one half each) then hit 16
 // different bank quads with unpadded rows, which is what lets the tiles arrive by global_load_lds (a wave's 64 x 16 bytes land
 // in 64 consecutive slots; the swizzle is applied to the per-lane SOURCE address).
-template <int NPL>
-__global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(const ConvParams p)
+//
+// TH = tile rows = 2 per wave: 8 (256 threads, two workgroups per CU) or 16 (512 threads, one per CU).  The weight tile of a step
+// is shared by all the workgroup's waves, so the taller tile halves the weight bytes copied per MFMA -- and the copies are what
+// the kernel is short of: with the MFMAs taken out the 8-row kernel still runs 45 % of its time (its copies pull ~9 TB/s out of
+// L2), and only a third of that hides behind the matrix work.
+//
+// D = how many steps ahead the weight copies run (D + 1 buffers).  A copy has to cross L2 under the load of every other CU's
+// copies: two steps (~1.3 us) is about its latency, so the counted wait in front of the barrier regularly stalls on it; four
+// steps (the 16-row kernel has the LDS for five buffers) take it off the critical path.  D > 2 needs ntaps >= D (then the
+// activation tile of the next chunk, issued at the chunk's first tap, is always older than the weights a step waits for).
+template <int NPL, int TH, int D>
+__global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
+    constexpr int UC_NBBUF = D + 1;
+    constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
+    static_assert(TH == 8 || (TH == 16 && NPL == 2), "16-row tiles: two pieces (LDS)");
     constexpr int A_PIECES = NPL * UC_HP * 2;
     constexpr int A_PER = (A_PIECES + UC_THREADS - 1) / UC_THREADS;      // copy instructions per thread and chunk (6 / 8)
     constexpr int A_SLOTS = A_PER * UC_THREADS;                           // padded: every wave issues the same number of copies
     constexpr int A_BYTES = A_SLOTS * 16;
-    constexpr int B_PER = NPL;                                            // NPL * 256 slots / 256 threads
+    constexpr int B_PER = NPL * 256 / UC_THREADS;                         // weight slots per thread (NPL * 256 slots)
+    static_assert(B_PER * UC_THREADS == NPL * 256, "weight slots divide evenly");
     constexpr int B_BYTES = NPL * 256 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the copies go to M0 without a waterfall loop)
     const int tilesX = p.W / UC_TW;
-    const int tile = blockIdx.x, ty0 = (tile / tilesX) * UC_TH, tx0 = (tile % tilesX) * UC_TW;
+    const int tile = blockIdx.x, ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * UC_TW;
     const int nblk = blockIdx.y, nblks = p.cout / UC_BN;
     const int cin = p.c0 + p.c1, nchunks = cin / UC_KC, nsteps = nchunks * p.ntaps;
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
@@ -123,13 +135,15 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
             __builtin_amdgcn_global_load_lds(g, dst + u * UC_THREADS * 16, 16, 0, 0);
         }
     };
-    // weight slot q = u * 256 + tid = (plane u, n = tid / 2, stored half tid & 1)
-    const int b_src = (tid >> 1) * UC_KC + (((tid & 1) ^ ((tid >> 4) & 1))) * 8;      // element offset inside a plane's [128][16] tile
+    // weight slot q = u * THREADS + tid = (plane q / 256, n = (q % 256) / 2, stored half q & 1)
+    const int bq = tid & 255;
+    const int b_src = (tid >> 8) * (UC_BN * UC_KC) + (bq >> 1) * UC_KC + (((bq & 1) ^ ((bq >> 4) & 1))) * 8;   // element offset inside the step's tile
     auto copy_b = [&](int chunk, int tap, int buf) {
         const uint16_t *src = p.w + (((long)tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC) + b_src;
         lds_byte *dst = (lds_byte *)(sB + buf * B_BYTES + wave * 64 * 16);
 #pragma unroll
-        for (int u = 0; u < B_PER; ++u) __builtin_amdgcn_global_load_lds(src + u * (UC_BN * UC_KC), dst + u * UC_THREADS * 16, 16, 0, 0);
+        for (int u = 0; u < B_PER; ++u)
+            __builtin_amdgcn_global_load_lds(src + u * (UC_THREADS / 256) * (UC_BN * UC_KC), dst + u * UC_THREADS * 16, 16, 0, 0);
     };
 
     f32x16 acc[2][4];
@@ -140,22 +154,21 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    // prologue: activation chunk 0, weight steps 0 and 1
+    // prologue: activation chunk 0, weight steps 0 .. D-1
     copy_a(0, 0);
-    copy_b(0, 0, 0);
-    if (nsteps > 1) copy_b(1 / p.ntaps, 1 % p.ntaps, 1);
+    for (int s0 = 0; s0 < D && s0 < nsteps; ++s0) copy_b(s0 / p.ntaps, s0 % p.ntaps, s0);
     uc_wait_barrier<0>();
 
     const int r = lane & 31, h = lane >> 5;
     const int b_row = r * 2 + (h ^ ((r >> 3) & 1));          // slot of this lane's weight fragment inside a plane's 32 rows
     int step = 0;
-    int nc = 2 / p.ntaps, nt = 2 % p.ntaps;                  // (chunk, tap) of step + 2
-    int buf0 = 0, buf1 = 1, buf2 = 2;                        // weight buffers of steps s, s + 1, s + 2 (no division in the loop)
+    int nc = D / p.ntaps, nt = D % p.ntaps;                  // (chunk, tap) of step + D
+    int buf0 = 0, buf2 = D;                                  // weight buffers of steps s and s + D (no division in the loop)
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
             // copies: the next chunk's activations at the chunk's first tap, the weights of step + 2
             const bool issue_a = tap == 0 && chunk + 1 < nchunks;
-            const bool issue_b = step + 2 < nsteps;
+            const bool issue_b = step + D < nsteps;
             if (issue_a) copy_a(chunk + 1, (chunk + 1) & 1);
             if (issue_b) copy_b(nc, nt, buf2);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
@@ -180,21 +193,39 @@ __global__ void __launch_bounds__(UC_THREADS, NPL == 2 ? 2 : 1) k_unet_conv(cons
 #define UC_PRODUCT(PA, PB)                                                                                      \
     _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[n][PB], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
             if constexpr (NPL == 3) { UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2) }
             UC_PRODUCT(1, 0)
             UC_PRODUCT(0, 1)
             UC_PRODUCT(0, 0)
+            __builtin_amdgcn_s_setprio(0);
 #undef UC_PRODUCT
             // Before the barrier the weights of step + 1 must have landed (issued one step ago, before everything issued in
             // this step) and, when the next step opens a new chunk, its activations too.  Issue order inside a step is
             // activations first, weights second, so "at most B_PER outstanding" also covers the activations.
-            const bool need_a_now = issue_a && p.ntaps == 1;
-            if (issue_b) {
-                if (issue_a && !need_a_now) uc_wait_barrier<A_PER + B_PER>(); else uc_wait_barrier<B_PER>();
+            if constexpr (D == 2) {
+                const bool need_a_now = issue_a && p.ntaps == 1;
+                if (issue_b) {
+                    if (issue_a && !need_a_now) uc_wait_barrier<A_PER + B_PER>(); else uc_wait_barrier<B_PER>();
+                } else {
+                    if (issue_a && !need_a_now) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>();
+                }
             } else {
-                if (issue_a && !need_a_now) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>();
+                // newer than the weights of step + 1: the weight copies of steps step + 2 .. step + D that exist, and the next
+                // chunk's activations while the chunk is younger than D - 1 taps (ntaps >= D: they are due much later)
+                const int left = nsteps - (step + 2);
+                const int nb = left < 0 ? 0 : (left > D - 1 ? D - 1 : left);
+                const bool a_out = tap <= D - 2 && chunk + 1 < nchunks;
+#define UC_WAIT_CASE(NB_) case NB_: if (a_out) uc_wait_barrier<NB_ * B_PER + A_PER>(); else uc_wait_barrier<NB_ * B_PER>(); break;
+                switch (nb) {
+                    UC_WAIT_CASE(0) UC_WAIT_CASE(1) UC_WAIT_CASE(2)
+                    default: if (a_out) uc_wait_barrier<(D - 1) * B_PER + A_PER>(); else uc_wait_barrier<(D - 1) * B_PER>(); break;
+                }
+#undef UC_WAIT_CASE
+                static_assert(D <= 4, "wait cases cover D <= 4");
             }
-            { const int t0 = buf0; buf0 = buf1; buf1 = buf2; buf2 = t0; }
+            buf0 = buf0 + 1 == UC_NBBUF ? 0 : buf0 + 1;
+            buf2 = buf2 + 1 == UC_NBBUF ? 0 : buf2 + 1;
         }
     }
 

@@ -128,9 +128,19 @@ __global__ void __launch_bounds__(256) k_ws_count_other(const double *__restrict
 }
 
 // ---- markers: label(local_minima(image)) ---------------------------------------------------------------------------
+// Equal-valued neighbours belong to one plateau.  On a two-valued image (the U-Net tail's boundary map) the plateau of the
+// MAXIMUM is one giant network that can never be a minimum (it touches the other value somewhere): its pixels stay out of the
+// union-find -- hundreds of thousands of unions onto one root were 0.65 ms of contention -- and k_ws_lower_flags marks every one
+// of them as "has a lower neighbour".  Whether the image is two-valued is read from the device-side scalars of the two
+// reductions that ran just before (no host round trip).
 struct SameF64 {
     const double *v;
-    __device__ __forceinline__ bool valid(int) const { return true; }
+    const WsInfo *info;
+    __device__ __forceinline__ bool two_valued_max(int i) const
+    {
+        return info->n_other == 0 && info->emin != info->emax && enc_f64(v[i]) == info->emax;
+    }
+    __device__ __forceinline__ bool valid(int i) const { return !two_valued_max(i); }
     __device__ __forceinline__ bool same(int i, int j) const { return v[i] == v[j]; }
 };
 
@@ -149,6 +159,7 @@ __global__ void __launch_bounds__(256) k_ws_lower_flags(const double *__restrict
     if (x < X - 1 && v[i + 1] < h) bad = true;
     if (y < Y - 1 && v[i + X] < h) bad = true;
     if ((y == 0 || x == 0 || y == Y - 1 || x == X - 1) && enc_f64(h) == info->emax) bad = true;
+    if (info->n_other == 0 && info->emin != info->emax && enc_f64(h) == info->emax) bad = true;   // (see SameF64: left out of the union-find)
     // (one giant plateau -- the boundary network of a two-valued image -- would otherwise take hundreds of thousands of
     // same-address atomics; the flag only ever goes 0 -> 1, so a stale 0 just costs one more atomic)
     if (bad) { const int r = parent[i]; if (flag[r] == 0) atomicOr(&flag[r], 1); }
@@ -1105,7 +1116,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
     TIP_LAUNCH("ws_minmax", k_ws_minmax, dim3(min(WS_RED_BLOCKS, cdiv(n, 256))), dim3(256), 0, img, n, info);
     TIP_LAUNCH("ws_count_other", k_ws_count_other, dim3(min(WS_RED_BLOCKS, cdiv(n, 256))), dim3(256), 0, img, n, info);
     // markers
-    SameF64 same{img};
+    SameF64 same{img, info};
     int rc = uf_components(same, parent, Y, X);
     if (rc) return rc;
     TIP_HIP(hipMemsetAsync(flag, 0, n * sizeof(int), s));
@@ -1196,7 +1207,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                        (const int *)unordered, nnext, (const int *)drank, next_list);
             // fate of the generation: parallel passes that ping-pong the list of waiting pixels (no host round trip: every
             // pass is launched for the worst case and reads its count on the device), then the one-block tail
-            constexpr int MB_PASSES = 6;
+            constexpr int MB_PASSES = 3;     // (pixels wait only across collision fronts: the second pass is already nearly empty)
             TIP_HIP(hipMemsetAsync(pcount, 0, (MB_PASSES + 1) * sizeof(int), s));
             for (int pass = 0; pass < MB_PASSES; ++pass) {
                 int *dst = pass & 1 ? pendB : pendA;
