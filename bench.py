@@ -359,7 +359,19 @@ def main():
     use_dist = world > 1 or (os.environ.get("TIP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the ONE JSON line, so
+        # file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from tissue_image_processing_amd import _lib, synthetic
     from tissue_image_processing_amd.pipeline import FramePipeline

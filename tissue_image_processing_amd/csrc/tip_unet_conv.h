@@ -229,69 +229,97 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
         }
     }
 
-    // ---- epilogue: float32 bias [-> ReLU -> scale, shift], split, store -----------------------------------------------------
-    // A lane holds ONE output channel (r) of 16 pixels per accumulator tile.  Adjacent lanes (channels r, r ^ 1) trade one value
-    // of each register pair (x, x + 1) through a DPP swap, so that every lane stores two adjacent channels of one pixel: 4-byte
-    // stores, half as many as one per value.  With pool_out set (Conv2D followed by MaxPool2D(2), pl.py:42-43) the 2 x 2 window of
-    // a pooled pixel -- rows 2w, 2w + 1 of the wave, registers i, i + 1 -- lies in one lane: the pooled map is written from the
-    // same registers (the pieces of a value are a monotone function of the value, so max-then-split equals the pooled split map).
-    const long out_plane = (long)p.outH * p.outW * p.cout;
+    // ---- epilogue: float32 bias [-> ReLU -> scale, shift], split, store through LDS ------------------------------------------
+    // A lane holds ONE output channel of 16 pixels per accumulator tile: stored from the registers, a wave's store touches 64-byte
+    // pieces of many rows, and with the stores taken out the whole network ran 17 % faster -- the epilogue was bound by the store
+    // path, not by HBM.  So a tile row goes through the (now idle) LDS: v_cvt_pk_bf16_f32 rounds two neighbouring pixels of the
+    // lane's channel into one word (nearest even; the remainder stays in the accumulator for the next piece), adjacent lanes
+    // (channels r, r ^ 1) trade words through a DPP swap and a byte permute leaves every lane with two adjacent channels of ONE
+    // pixel, which it writes to a [32 pixels][128 channels] image (320-byte rows: the even and odd lanes of a half-wave hit
+    // disjoint banks); the image is read back in rows and leaves as 8 bytes per lane, 256 contiguous bytes per pixel.
+    // One (tile row, piece) at a time, 10 KB per wave.  With pool_out set (Conv2D followed by MaxPool2D(2), pl.py:42-43) the 2 x 2
+    // window of a pooled pixel -- rows 2w, 2w + 1 of the wave, registers i, i + 1 -- lies in one lane: the pooled map goes out the
+    // same way first (max-then-split equals the pooled split map: the pieces are a monotone function of the value).
+    constexpr int EP_ROW = 320, EP_BYTES = (NPL * 16 > 32 ? NPL * 16 : 32) * EP_ROW;
+    static_assert(UC_THREADS / 64 * EP_BYTES <= 2 * A_BYTES + UC_NBBUF * B_BYTES, "the staging images fit the tile buffers");
+    __syncthreads();                                  // every wave has left the main loop: the tile buffers are free
     int re = r, he = h;
-    asm volatile("" : "+v"(re), "+v"(he));      // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
+    asm volatile("" : "+v"(re), "+v"(he));            // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
+    unsigned char *ep = smem + wave * EP_BYTES;
     const bool odd = re & 1;
-    const unsigned perm_sel = odd ? 0x03020706u : 0x05040100u;       // v_perm_b32 selector, see store_pair
+    const unsigned perm_sel = odd ? 0x03020706u : 0x05040100u;       // even lanes: (own a, neighbour's a); odd: (neighbour's b, own b)
     auto swap_lanes = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
-    // Values a (pixel xa) and b (pixel xa + 1) of this lane's channel.  v_cvt_pk_bf16_f32 rounds both to bf16 (nearest even) into
-    // one word (a low, b high); the remainder a - bf16(a) is exact in float32 and gives the next piece.  The word is traded with the
-    // neighbouring lane and one byte permute builds what this lane stores: even lanes pixel xa, channels (r, r + 1) = (own a,
-    // neighbour's a); odd lanes pixel xa + 1, channels (r - 1, r) = (neighbour's b, own b).
-    auto store_pair = [&](uint16_t *row_base, long plane_stride, long px_stride, float a, float b) {
-        uint16_t *o = row_base + (odd ? px_stride - 1 : 0);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            bf16x2 hv;
-            hv[0] = (__bf16)a;
-            hv[1] = (__bf16)b;
-            const unsigned mine = __builtin_bit_cast(unsigned, hv);
-            if (pl + 1 < NPL) {
-                a -= __uint_as_float(mine << 16);
-                b -= __uint_as_float(mine & 0xffff0000u);
-            }
-            const unsigned theirs = swap_lanes(mine);
-            *reinterpret_cast<unsigned *>(o + pl * plane_stride) = __builtin_amdgcn_perm(theirs, mine, perm_sel);
+    // rounds (a, b) to the next piece, keeps the remainders when more pieces follow, returns this lane's word of the image
+    auto piece_word = [&](float &a, float &b, bool more) -> unsigned {
+        bf16x2 hv;
+        hv[0] = (__bf16)a;
+        hv[1] = (__bf16)b;
+        const unsigned mine = __builtin_bit_cast(unsigned, hv);
+        if (more) {
+            a -= __uint_as_float(mine << 16);
+            b -= __uint_as_float(mine & 0xffff0000u);
         }
+        return __builtin_amdgcn_perm(swap_lanes(mine), mine, perm_sel);
     };
-    const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
+    const int lrow = lane >> 5, lcol = lane & 31;     // read-back: half-wave = one image row, 8 bytes per lane
+    const long out_plane = (long)p.outH * p.outW * p.cout;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int co = nblk * UC_BN + n * 32 + re;
         const float b = p.bias[co];
         const float sc = p.scale ? p.scale[co] : 1.f, sh = p.scale ? p.shift[co] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int y = ty0 + wave * 2 + m;
-            uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + p.ox) * p.cout + co;
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float v = acc[m][n][i] + b;
                 if (p.scale) { v = v > 0.f ? v : 0.f; v = v * sc + sh; }
                 acc[m][n][i] = v;
             }
+    }
+    if (p.pool_out) {
+        const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const int x = tx0 + (i & 3) + 8 * (i >> 2) + 4 * he;
-                store_pair(orow + (long)(x * p.sx) * p.cout, out_plane, (long)p.sx * p.cout, acc[m][n][i], acc[m][n][i + 1]);
-            }
-        }
-        if (p.pool_out) {
-            const int yo = ty0 / 2 + wave;
-            uint16_t *prow = p.pool_out + ((long)yo * (p.outW / 2)) * p.cout + co;
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int i = 0; i < 16; i += 4) {      // registers i .. i + 3: pixels x .. x + 3 -> pooled pixels x / 2, x / 2 + 1
-                const int xo = (tx0 + 8 * (i >> 2) + 4 * he) / 2;
-                const float q0 = fmaxf(fmaxf(acc[0][n][i], acc[0][n][i + 1]), fmaxf(acc[1][n][i], acc[1][n][i + 1]));
-                const float q1 = fmaxf(fmaxf(acc[0][n][i + 2], acc[0][n][i + 3]), fmaxf(acc[1][n][i + 2], acc[1][n][i + 3]));
-                store_pair(prow + (long)xo * p.cout, pool_plane, (long)p.cout, q0, q1);
+                float q0 = fmaxf(fmaxf(acc[0][n][i], acc[0][n][i + 1]), fmaxf(acc[1][n][i], acc[1][n][i + 1]));
+                float q1 = fmaxf(fmaxf(acc[0][n][i + 2], acc[0][n][i + 3]), fmaxf(acc[1][n][i + 2], acc[1][n][i + 3]));
+                const int row = 4 * (i >> 2) + 2 * he + (odd ? 1 : 0);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    *reinterpret_cast<unsigned *>(ep + (pl * 16 + row) * EP_ROW + ((n * 32 + re) >> 1) * 4) = piece_word(q0, q1, pl + 1 < NPL);
+            }
+        uint16_t *prow = p.pool_out + ((long)(ty0 / 2 + wave) * (p.outW / 2) + tx0 / 2) * p.cout + nblk * UC_BN + lcol * 4;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 2 + lrow;
+                *reinterpret_cast<uint2 *>(prow + pl * pool_plane + (long)row * p.cout) =
+                    *reinterpret_cast<const uint2 *>(ep + (pl * 16 + row) * EP_ROW + lcol * 8);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = ty0 + wave * 2 + m;
+        uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + ((long)tx0 * p.sx + p.ox)) * p.cout + nblk * UC_BN + lcol * 4;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * he + (odd ? 1 : 0);
+                    float va = acc[m][n][i], vb = acc[m][n][i + 1];        // (vector elements do not bind to references)
+                    *reinterpret_cast<unsigned *>(ep + row * EP_ROW + ((n * 32 + re) >> 1) * 4) = piece_word(va, vb, pl + 1 < NPL);
+                    acc[m][n][i] = va;
+                    acc[m][n][i + 1] = vb;
+                }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 2 + lrow;
+                *reinterpret_cast<uint2 *>(orow + pl * out_plane + (long)row * p.sx * p.cout) = *reinterpret_cast<const uint2 *>(ep + row * EP_ROW + lcol * 8);
             }
         }
     }
