@@ -183,19 +183,22 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     // weight buffers (copies four steps ahead) when the stencil has >= 4 taps; two pieces only (LDS)
     const int th = (d->planes == 2 && d->h % 16 == 0 && !tuning().unet_tile8) ? 16 : 8;
     const int dist = (th == 16 && d->ntaps >= 4) ? 4 : 2;
+    const int da = (th == 16 && d->ntaps <= 2) ? 2 : 1;       // one- and two-tap stencils: activation tiles two chunks ahead
     const int threads = th * 32, hp = UC_HW * (th + 2);
     const dim3 grid((d->h / th) * (d->w / UC_TW), d->cout / UC_BN);
     const int a_per = (d->planes * hp * 2 + threads - 1) / threads;
-    const size_t lds = 2 * (size_t)a_per * threads * 16 + (size_t)(dist + 1) * d->planes * 256 * 16;
+    const size_t lds = (size_t)(da + 1) * a_per * threads * 16 + (size_t)(dist + 1) * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set[4] = {false, false, false, false};
-    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? 2 : 1) : 0);
+    static bool attr_set[5] = {false, false, false, false, false};
+    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? 2 : (da == 2 ? 4 : 1)) : 0);
     const void *fn = which == 3 ? (const void *)k_unet_conv<3, 8, 2>
                    : which == 2 ? (const void *)k_unet_conv<2, 16, 4>
+                   : which == 4 ? (const void *)k_unet_conv<2, 16, 2, 2>
                    : which == 1 ? (const void *)k_unet_conv<2, 16, 2> : (const void *)k_unet_conv<2, 8, 2>;
     if (!attr_set[which]) { TIP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[which] = true; }
     if (which == 3) hipLaunchKernelGGL((k_unet_conv<3, 8, 2>), grid, dim3(threads), lds, s, p);
     else if (which == 2) hipLaunchKernelGGL((k_unet_conv<2, 16, 4>), grid, dim3(threads), lds, s, p);
+    else if (which == 4) hipLaunchKernelGGL((k_unet_conv<2, 16, 2, 2>), grid, dim3(threads), lds, s, p);
     else if (which == 1) hipLaunchKernelGGL((k_unet_conv<2, 16, 2>), grid, dim3(threads), lds, s, p);
     else hipLaunchKernelGGL((k_unet_conv<2, 8, 2>), grid, dim3(threads), lds, s, p);
     return unet_launch_check("unet_conv");
@@ -206,9 +209,9 @@ int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, con
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || ((long)h * w) % 64 || (planes != 2 && planes != 3))
+    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || ((long)h * w) % 16 || (planes != 2 && planes != 3))
         return fail(TIP_ERR_ARG, "tip_unet_conv_first_dev: bad arguments");
-    const dim3 grid((unsigned)((long)h * w / 64));
+    const dim3 grid((unsigned)((long)h * w / 16));
     hipStream_t s = (hipStream_t)stream;
     if (planes == 2) hipLaunchKernelGGL(k_unet_conv_first<2>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
     else hipLaunchKernelGGL(k_unet_conv_first<3>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);

@@ -91,9 +91,14 @@ __device__ __forceinline__ void uc_wait_barrier()
 // copies: two steps (~1.3 us) is about its latency, so the counted wait in front of the barrier regularly stalls on it; four
 // steps (the 16-row kernel has the LDS for five buffers) take it off the critical path.  D > 2 needs ntaps >= D (then the
 // activation tile of the next chunk, issued at the chunk's first tap, is always older than the weights a step waits for).
-template <int NPL, int TH, int D>
+//
+// DA = how many chunks ahead the activation copies run (DA + 1 buffers): one is enough for a 3x3 stencil (nine steps of flight);
+// with one or two taps per chunk -- the small parity classes of the transposed convolution -- the tile issued at a chunk's first
+// tap is due one or two steps later and the wave sat on it, so those run two chunks ahead (DA = 2 needs D = 2).
+template <int NPL, int TH, int D, int DA = 1>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
+    static_assert(DA == 1 || (DA == 2 && D == 2), "two-chunk activation prefetch: with the two-step weight schedule");
     constexpr int UC_NBBUF = D + 1;
     constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
     static_assert(TH == 8 || (TH == 16 && NPL == 2), "16-row tiles: two pieces (LDS)");
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     static_assert(B_PER * UC_THREADS == NPL * 256, "weight slots divide evenly");
     constexpr int B_BYTES = NPL * 256 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
+    unsigned char *sA = smem, *sB = smem + (DA + 1) * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the copies go to M0 without a waterfall loop)
     const int tilesX = p.W / UC_TW;
@@ -156,6 +161,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
 
     // prologue: activation chunk 0, weight steps 0 .. D-1
     copy_a(0, 0);
+    if (DA == 2 && nchunks > 1) copy_a(1, 1);
     for (int s0 = 0; s0 < D && s0 < nsteps; ++s0) copy_b(s0 / p.ntaps, s0 % p.ntaps, s0);
     uc_wait_barrier<0>();
 
@@ -167,12 +173,12 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
             // copies: the next chunk's activations at the chunk's first tap, the weights of step + 2
-            const bool issue_a = tap == 0 && chunk + 1 < nchunks;
+            const bool issue_a = tap == 0 && chunk + DA < nchunks;
             const bool issue_b = step + D < nsteps;
-            if (issue_a) copy_a(chunk + 1, (chunk + 1) & 1);
+            if (issue_a) copy_a(chunk + DA, (chunk + DA) % (DA + 1));
             if (issue_b) copy_b(nc, nt, buf2);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
-            const unsigned char *abuf = sA + (chunk & 1) * A_BYTES;
+            const unsigned char *abuf = sA + (chunk % (DA + 1)) * A_BYTES;
             const unsigned char *bbuf = sB + buf0 * B_BYTES;
             const int dy = p.dy[tap], dx = p.dx[tap];
             bf16x8 fa[2][NPL], fb[4][NPL];
@@ -204,7 +210,8 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             // this step) and, when the next step opens a new chunk, its activations too.  Issue order inside a step is
             // activations first, weights second, so "at most B_PER outstanding" also covers the activations.
             if constexpr (D == 2) {
-                const bool need_a_now = issue_a && p.ntaps == 1;
+                // (DA == 2: the tile the next step may need was issued at least a step ago, before the weights waited for here)
+                const bool need_a_now = DA == 1 && issue_a && p.ntaps == 1;
                 if (issue_b) {
                     if (issue_a && !need_a_now) uc_wait_barrier<A_PER + B_PER>(); else uc_wait_barrier<B_PER>();
                 } else {
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     // window of a pooled pixel -- rows 2w, 2w + 1 of the wave, registers i, i + 1 -- lies in one lane: the pooled map goes out the
     // same way first (max-then-split equals the pooled split map: the pieces are a monotone function of the value).
     constexpr int EP_ROW = 320, EP_BYTES = (NPL * 16 > 32 ? NPL * 16 : 32) * EP_ROW;
-    static_assert(UC_THREADS / 64 * EP_BYTES <= 2 * A_BYTES + UC_NBBUF * B_BYTES, "the staging images fit the tile buffers");
+    static_assert(UC_THREADS / 64 * EP_BYTES <= (DA + 1) * A_BYTES + UC_NBBUF * B_BYTES, "the staging images fit the tile buffers");
     __syncthreads();                                  // every wave has left the main loop: the tile buffers are free
     int re = r, he = h;
     asm volatile("" : "+v"(re), "+v"(he));            // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
@@ -326,18 +333,19 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
 }
 
 // ---- first layer: Conv2D(2 -> 128, 3x3) on the float32 (2, H, W) network input --------------------------------------------------
-// K = 18: nothing for the matrix cores; exact float32 FMAs, one wave per 64 pixels x 32 output channels (the wave's lanes share
-// every weight: LDS broadcast), the same epilogue and split as the MFMA kernel.
+// K = 18: nothing for the matrix cores -- the layer is its 2.1 GB of output.  Exact float32 FMAs; a thread owns 8 adjacent output
+// channels of one pixel, sixteen threads a pixel, so a wave's stores are 1 KB contiguous per piece (four pixels x 256 bytes) and
+// the split of two adjacent channels is one v_cvt_pk_bf16_f32 (no lane exchange).  Weights [18][128] in LDS, read as float4.
 template <int NPL>
 __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict__ in, int H, int W, const float *__restrict__ wgt /* [9][2][128] */,
                                                          const float *__restrict__ bias, const float *__restrict__ scale,
                                                          const float *__restrict__ shift, uint16_t *__restrict__ out)
 {
-    __shared__ float sw[18 * 128];
+    __shared__ __attribute__((aligned(16))) float sw[18 * 128];
     for (int i = threadIdx.x; i < 18 * 128; i += 256) sw[i] = wgt[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const long pix = (long)blockIdx.x * 64 + lane;
+    const int cg = threadIdx.x & 15;
+    const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
     float v[18];
 #pragma unroll
@@ -349,31 +357,46 @@ __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict
         v[2 * t] = inside ? a : 0.f;
         v[2 * t + 1] = inside ? b : 0.f;
     }
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * 128 + cg * 8), w1 = *reinterpret_cast<const float4 *>(sw + k * 128 + cg * 8 + 4);
+        a[0] = __builtin_fmaf(v[k], w0.x, a[0]); a[1] = __builtin_fmaf(v[k], w0.y, a[1]);
+        a[2] = __builtin_fmaf(v[k], w0.z, a[2]); a[3] = __builtin_fmaf(v[k], w0.w, a[3]);
+        a[4] = __builtin_fmaf(v[k], w1.x, a[4]); a[5] = __builtin_fmaf(v[k], w1.y, a[5]);
+        a[6] = __builtin_fmaf(v[k], w1.z, a[6]); a[7] = __builtin_fmaf(v[k], w1.w, a[7]);
+    }
+    const float4 b0 = *reinterpret_cast<const float4 *>(bias + cg * 8), b1 = *reinterpret_cast<const float4 *>(bias + cg * 8 + 4);
+    const float4 s0 = *reinterpret_cast<const float4 *>(scale + cg * 8), s1 = *reinterpret_cast<const float4 *>(scale + cg * 8 + 4);
+    const float4 t0 = *reinterpret_cast<const float4 *>(shift + cg * 8), t1 = *reinterpret_cast<const float4 *>(shift + cg * 8 + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float r = a[j] + bb[j];
+        r = r > 0.f ? r : 0.f;
+        a[j] = r * ss[j] + tt[j];
+    }
     const long plane = (long)H * W * 128;
-    uint16_t *dst = out + pix * 128 + cg * 32;
+    uint16_t *dst = out + pix * 128 + cg * 8;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {          // 8 output channels at a time: one 16-byte store per plane
-        unsigned pk[NPL][4];
+    for (int pl = 0; pl < NPL; ++pl) {
+        unsigned wd[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = cg * 32 + g * 8 + j;
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) a = __builtin_fmaf(v[k], sw[k * 128 + co], a);
-            a += bias[co];
-            a = a > 0.f ? a : 0.f;
-            a = a * scale[co] + shift[co];
-            float rest = a;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                const unsigned hb = bf16_rne_bits(rest);
-                rest -= bf16_bits_to_f32(hb);
-                if (j & 1) pk[pl][j >> 1] |= hb << 16; else pk[pl][j >> 1] = hb;
+        for (int q = 0; q < 4; ++q) {
+            bf16x2 hv;
+            hv[0] = (__bf16)a[2 * q];
+            hv[1] = (__bf16)a[2 * q + 1];
+            wd[q] = __builtin_bit_cast(unsigned, hv);
+            if (pl + 1 < NPL) {
+                a[2 * q] -= __uint_as_float(wd[q] << 16);
+                a[2 * q + 1] -= __uint_as_float(wd[q] & 0xffff0000u);
             }
         }
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-            *reinterpret_cast<uint4 *>(dst + pl * plane + g * 8) = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+        *reinterpret_cast<uint4 *>(dst + pl * plane) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
 }
 
