@@ -303,7 +303,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps of the headline leg (default: 12 for the U-Net workload, 64 for classical / projection, "
+                    help="timed steps of the headline leg (default: 16 for the U-Net workload, 64 for classical / projection, "
                          "16 for --workload movie, whose every frame is a distinct synthetic stack kept in pinned memory)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 3 for the U-Net workload, else 8)")
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
@@ -320,7 +320,7 @@ def main():
     args = ap.parse_args()
     workload = "unet" if args.workload == "auto" else args.workload
     if args.steps is None:
-        args.steps = {"movie": 16, "unet": 12}.get(workload, 64)
+        args.steps = {"movie": 16, "unet": 16}.get(workload, 64)
     if args.warmup is None:
         args.warmup = 3 if workload == "unet" else 8
     if args.gpus < 1:
