@@ -667,6 +667,17 @@ def main():
              "flops_per_frame": flops, "peak": info["peak_tflops"], "unit": "TFLOP/s", "forward_ms": fwd_ms,
              "achieved": None, "frac": None, "traffic": None,
              "measured": "events around the network's forward pass on its stream, isolated pass (one frame in flight), median of %d" % len(ms)}
+        # HBM bytes of the network's kernels from the committed counter passes (FETCH_SIZE x 2 + WRITE_SIZE over one forward pass)
+        import glob
+        tr_paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_unet_pmc_traffic.json")))
+        if tr_paths and (hp, wp) == (2048, 2048) and info.get("issued_flops_factor", 1) == 3:
+            recs = json.load(open(tr_paths[-1]))
+            tot = sum((v["fetch_MB_per_call_x2corrected"] + v["write_MB_per_call"]) * v["calls"] for k, v in recs.items() if k.startswith("k_unet_"))
+            passes = max(1, min(v["calls"] for k, v in recs.items() if k.startswith("k_unet_head")))
+            r["traffic"] = tot * 1e6 / passes
+            r["algorithmic_bytes"] = plm.unet_algorithmic_bytes(hp, wp)
+            r["traffic_ratio"] = r["traffic"] / r["algorithmic_bytes"]
+            r["traffic_source"] = os.path.basename(tr_paths[-1])
         if fwd_ms:
             r["achieved"] = flops / (fwd_ms / 1e3) / 1e12
             r["frac"] = r["achieved"] / info["peak_tflops"]

@@ -90,6 +90,29 @@ def unet_arithmetic():
                           "peak / %d" % (2 if prods == 3 else 3, prods, "1.6e-5" if prods == 3 else "9e-8", prods)}
 
 
+def unet_algorithmic_bytes(h, w):
+    """Compulsory HBM bytes of one forward pass at float32 width (every layer's input read once, its output written once, the
+    split weights read once): what `roofline.traffic` of the network's kernels is compared with."""
+    total = 0
+    c, hh, ww = 2, h, w
+    layers = []
+    for f in _FILTERS:
+        layers += [(hh, ww, c, f), (hh, ww, f, f)]
+        c, hh, ww = f, hh // 2, ww // 2
+    layers += [(hh, ww, c, 1024), (hh, ww, 1024, 1024)]
+    c = 1024
+    for f in reversed(_FILTERS):
+        total += 4 * (hh * ww * c + 4 * hh * ww * f) + 4 * 9 * c * f          # transposed convolution: in, out (2h x 2w), weights
+        hh, ww = hh * 2, ww * 2
+        layers += [(hh, ww, 2 * f, f), (hh, ww, f, f)]
+        c = f
+    for (lh, lw, ci, co) in layers:
+        total += 4 * lh * lw * (ci + co) + 4 * 9 * ci * co
+    total += 4 * hh * ww * (c + 2)                                            # head
+    total += 4 * sum((h >> (i + 1)) * (w >> (i + 1)) * f for i, f in enumerate(_FILTERS))   # pooled maps (written by the conv epilogue)
+    return total
+
+
 class _ConvDesc(ctypes.Structure):
     """tip_unet_conv_desc of include/tissue_hip.h."""
     _fields_ = [("in0", ctypes.c_void_p), ("in1", ctypes.c_void_p), ("c0", ctypes.c_int), ("c1", ctypes.c_int), ("h", ctypes.c_int),

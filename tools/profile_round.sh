@@ -26,6 +26,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/su -o su -- python3
 echo "stats unet done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pm -o pm -- python3 bench.py --workload unet --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-secondary-leg --no-pcie-leg > $out/pm.json 2> $out/pm.err || exit 1
 echo "pmc mfma done"
+# HBM traffic of the network's kernels (the headline's dominant kernel group): one forward pass per launch of tools/unet_layers.py
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/uf -o uf -- python3 tools/unet_layers.py 2048 > $out/uf.log 2> $out/uf.err || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/uw -o uw -- python3 tools/unet_layers.py 2048 > $out/uw.log 2> $out/uw.err || exit 1
+echo "pmc unet traffic done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $out/ps -o ps -- python3 bench.py --workload projection --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-pcie-leg > $out/ps.json 2> $out/ps.err || exit 1
 echo "pmc mfma (score passes) done"
 cp $(find $out/s1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_inflight1.csv
@@ -33,6 +37,7 @@ cp $(find $out/s3 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_
 cp $(find $out/su -name "*kernel_stats.csv" | head -1) $out/${tag}_unet_kernel_stats.csv
 f=$(find $out/pf -name "*counter_collection.csv" | head -1); w=$(find $out/pw -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $f $w $out/${tag}_pmc_traffic.json
+python3 tools/pmc_summary.py "$(find $out/uf -name '*counter_collection.csv' | head -1)" "$(find $out/uw -name '*counter_collection.csv' | head -1)" $out/${tag}_unet_pmc_traffic.json
 for pair in "$f:$out/${tag}_pmc_fetch_size.csv" "$w:$out/${tag}_pmc_write_size.csv"; do
 python3 - "${pair%%:*}" "${pair##*:}" <<'PY'
 import sys, csv
@@ -68,5 +73,5 @@ PY
 python3 $out/mfma_busy.py "$(find $out/pm -name '*counter_collection.csv' | head -1)" "$out/${tag}_unet_mfma_busy.json"
 python3 $out/mfma_busy.py "$(find $out/ps -name '*counter_collection.csv' | head -1)" "$out/${tag}_score_mfma_busy.json"
 rm -f $out/mfma_busy.py
-rm -rf $out/s1 $out/s3 $out/pf $out/pw $out/su $out/pm $out/ps
+rm -rf $out/s1 $out/s3 $out/pf $out/pw $out/su $out/pm $out/ps $out/uf $out/uw
 ls -la $out
