@@ -151,7 +151,8 @@ TIP_API int tip_stream_wait_tip(void *stream);
 typedef struct tip_unet_conv_desc {
     const void *in0, *in1;      /* split activations; in1 (c1 channels) is appended to in0's channels: concatenate   */
     int c0, c1, h, w, planes;   /* channels (multiples of 16), input grid (multiples of 8 x 32), pieces per value     */
-    const void *weights;        /* packed split weights [tap][cin/16][cout/128][plane][128][16] bf16                  */
+    const void *weights;        /* packed split weights [tap][cin/16][cout/128][plane][128][16] bf16; in every group of 32    */
+                                /* output channels row 8g + 4h + j (g < 4, h < 2, j < 4) holds channel 16h + 4g + j            */
     int ntaps, dy[9], dx[9];    /* taps: input offset (-1, 0, 1) each; Conv2D 3x3: the nine offsets in kernel order   */
     int cout;                   /* multiple of 128                                                                     */
     const float *bias, *scale, *shift;   /* scale / shift NULL: bias only (Conv2DTranspose); else bias -> ReLU -> BN */
@@ -159,6 +160,8 @@ typedef struct tip_unet_conv_desc {
     int out_h, out_w, sy, sx, oy, ox;
     void *pool_out;             /* NULL, or [plane][out_h / 2][out_w / 2][cout]: MaxPool2D(2) of the output, written from  */
                                 /* the same registers (Conv2D -> MaxPool2D, pl.py:42-43); needs sy = sx = 1, oy = ox = 0   */
+    const float *head_w, *head_b; /* NULL, or the network's head fused into this layer (cout == 128, plain mapping, BN present):  */
+    float *head_out;            /* Conv2D(128 -> 2, 1x1) weights [2][128], bias [2], softmax -> float32 (2, h, w); `out` unused    */
 } tip_unet_conv_desc;
 TIP_API int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream);
 /* first layer, Conv2D(2 -> 128): float32 (2, h, w) in, weights [9][2][128] float32, exact float32 FMAs               */
@@ -168,6 +171,12 @@ TIP_API int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes,
 /* Conv2D(128 -> 2, 1x1) + softmax: float32 (2, npix) out; logits != 0: the pre-softmax values                         */
 TIP_API int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int logits,
                               void *stream);
+/* U1, prepare_image + normalize_channel (pl.py:21-29, 90-122) on a device-resident image: img = (c, a, b) float64,       */
+/* element strides (cstride, sa, sb), every channel plane dense in either orientation; kind = dtype of the caller's image  */
+/* (0 float64, 1 float32, 2 integer: the clip values take it, pl.py:26-27).  Per channel: np.percentile 1 / 99 (exact order  */
+/* statistics by radix select + numpy's lerp), clip, scale; out = (c, bp, ap) float32, transposed, zero-padded in front.      */
+TIP_API int tip_unet_prepare_f64_dev(const double *img, int c, int a, int b, long cstride, long sa, long sb, int kind, float *out,
+                                     int ap, int bp, void *stream);
 /* pl.py:167-194 after the network, one submission: p = class-0 probability map on the device (y rows of x values, row  */
 /* pitch ld elements; dtype 0 = float32, 1 = float64) -> 255 (p > thr) -> 5x5 closing -> HC = 7x7 erosion -> boundary = */
 /* 5x5 dilation of (closed - HC) -> watershed(watershed_line=True).  labels / hc: caller-owned device buffers (y * x).  */

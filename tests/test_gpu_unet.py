@@ -46,6 +46,44 @@ def test_predict_shapes_and_padding():
     np.testing.assert_allclose(got, np.transpose(ref, (0, 2, 1)).astype(np.float32), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["f64", "f64_transposed_view", "f32", "u16", "ties", "one_pixel_rows"])
+def test_prepare_image_fused_pass_equals_torch_expressions(case, monkeypatch):
+    """U1 as one library submission (tip_unet_prepare_f64_dev: radix-select order statistics, numpy's lerp, clip / scale /
+    transpose / pad) against the torch expressions it replaces (sort + where + divide), bit for bit, for every input dtype rule
+    of normalize_channel (pl.py:21-29), both plane orientations, ragged extents and heavy value ties."""
+    import torch
+    from tissue_image_processing_amd import prediction_local as pl
+    rng = np.random.default_rng(11)
+    if case == "f64":
+        img = rng.random((2, 301, 423)) * 4000.0 - 100.0
+    elif case == "f64_transposed_view":
+        base = torch.as_tensor(rng.random((2, 260, 517)) * 900.0, device="cuda")
+        img = base.transpose(1, 2)                           # (C, 517, 260) view, first plane index with unit stride
+    elif case == "f32":
+        img = (rng.random((2, 129, 65)) * 70000.0).astype(np.float32)
+    elif case == "u16":
+        img = rng.integers(0, 4000, (2, 200, 333)).astype(np.uint16)
+    elif case == "ties":
+        img = rng.integers(0, 5, (3, 97, 131)).astype(np.float64)
+    else:
+        img = rng.random((1, 1, 700))
+    pred = pl.SegmentationPredictor(None, tuple(img.shape))
+    fused, npad = pred.prepare_image(img)
+    monkeypatch.setenv("TISSUE_HIP_PREPARE_TORCH", "1")
+    ref, npad_ref = pred.prepare_image(img)
+    assert npad == npad_ref and fused.shape == ref.shape and fused.dtype == ref.dtype
+    torch.cuda.synchronize()
+    if case == "f32":
+        # float32 arithmetic: numpy divides (pl.py:29), the fused pass divides, torch's tensor / scalar multiplies by the
+        # reciprocal -- one ulp apart on some pixels; the clip decisions and the pad are identical
+        np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=2.5e-7, atol=1e-7)
+        host = np.stack([pl.normalize_channel(img[c]) for c in range(img.shape[0])])       # numpy's own division
+        got = fused[0, :, npad[1][0]:, npad[2][0]:].cpu().numpy()
+        np.testing.assert_allclose(got, np.transpose(host, (0, 2, 1)), rtol=2.5e-7, atol=1e-7)
+    else:
+        assert torch.equal(fused, ref)
+
+
 class _FakeNet(object):
     """Stands in for the trained network (no weights ship with the reference): returns a fixed class-probability map."""
 

@@ -168,7 +168,7 @@ def test_hip_and_miopen_paths_segment_alike(arith):
 
 
 @pytest.mark.parametrize("shape", [(128, 512), (192, 256), (64, 768)])
-def test_network_hip_path_other_extents(shape, arith):
+def test_network_hip_path_other_extents(shape, arith, monkeypatch):
     """Extents that mix the kernel's tile flavours over the levels: 16-row tiles with the four-step weight schedule, 16-row
     tiles with the two-chunk activation schedule (one- and two-tap classes), 8-row tiles where a level's grid is not a multiple
     of 16 rows (192 -> 24 rows at the bottleneck), non-square frames; and the 8-row flavour forced everywhere."""
@@ -185,5 +185,14 @@ def test_network_hip_path_other_extents(shape, arith):
     err = float((gpu.forward(xg).cpu().double() - exp).abs().max())
     with _lib.tuning(TIP_UNET_TILE8="1"):
         err8 = float((gpu.forward(xg).cpu().double() - exp).abs().max())
-    print("%dx%d: max |dp| %.2e (8-row tiles everywhere: %.2e)" % (shape[0], shape[1], err, err8))
-    assert err < 2e-4 and err8 < 2e-4
+    with _lib.tuning(TIP_UNET_TILE8="0"):
+        err16 = float((gpu.forward(xg).cpu().double() - exp).abs().max())
+    # the head as its own kernel on the stored split planes (the default fuses it into the last convolution's epilogue)
+    fused = gpu.forward(xg)
+    monkeypatch.setenv("TISSUE_HIP_UNET_SEPARATE_HEAD", "1")
+    sep = gpu.forward(xg)
+    errsep = float((sep.cpu().double() - exp).abs().max())
+    dhead = float((sep - fused).abs().max())
+    print("%dx%d: max |dp| %.2e (8-row tiles everywhere: %.2e, 16-row wherever possible: %.2e, separate head: %.2e, fused vs separate head %.2e)"
+          % (shape[0], shape[1], err, err8, err16, errsep, dhead))
+    assert err < 2e-4 and err8 < 2e-4 and err16 < 2e-4 and errsep < 2e-4 and dhead < 5e-5

@@ -145,7 +145,7 @@ bool tuning_assign(Tuning &t, const char *name, const char *value)
     else if (n == "TIP_PROJECT_EXACT_SCORE") flag(t.project_exact_score, 0);
     else if (n == "TIP_PROJECT_DEBUG") flag(t.project_debug, 0);
     else if (n == "TIP_FAST_CFG") pair(t.fast_cfg_y, t.fast_cfg_x, def.fast_cfg_y, def.fast_cfg_x);
-    else if (n == "TIP_UNET_TILE8") flag(t.unet_tile8, 0);
+    else if (n == "TIP_UNET_TILE8") num(t.unet_tile8, def.unet_tile8);
     else return false;
     return true;
 }
@@ -254,6 +254,7 @@ int tip_shutdown(void)
     for (auto &e : c->free_events) (void)hipEventDestroy(e);
     if (c->edge_event) (void)hipEventDestroy(c->edge_event);
     if (c->zero_page) (void)hipFree(c->zero_page);
+    if (c->prep_ws) (void)hipFree(c->prep_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     g_ctx = nullptr;

@@ -26,6 +26,7 @@ struct Ctx {
     long last_ws_other = 0;   // ... and its number of pixels that are neither the image's minimum nor its maximum
     hipEvent_t edge_event = nullptr;   // tip_wait_stream / tip_stream_wait_tip
     void *zero_page = nullptr;         // 256 zero bytes on the device (tip_unet_conv_dev)
+    void *prep_ws = nullptr;           // order-statistic state of tip_unet_prepare_f64_dev (used on the caller's stream only)
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
@@ -64,7 +65,7 @@ struct Tuning {
     int project_generic = 0, project_unfused_preblur = 0, project_unfused_mask = 0;
     int project_exact_score = 0, project_debug = 0;
     int fast_cfg_y = -1, fast_cfg_x = -1;    // TIP_FAST_CFG=y,x
-    int unet_tile8 = 0;         // TIP_UNET_TILE8: the U-Net convolution's 8-row tiles everywhere (default: 16 rows where the grid allows)
+    int unet_tile8 = -1;        // TIP_UNET_TILE8: the U-Net convolution's tile rows: 1 = 8 everywhere, 0 = 16 where the grid allows, -1 (default) = 16 except for 3x3 layers with <= 128 input channels
 };
 const Tuning &tuning();
 

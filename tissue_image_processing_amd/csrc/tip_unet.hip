@@ -46,6 +46,176 @@ __global__ void __launch_bounds__(256) k_tail_sub(const double *__restrict__ a, 
     if (i < n) out[i] = a[i] - b[i];
 }
 
+
+// ---- U1: prepare_image (pl.py:21-29, 90-122) on a device-resident (C, A, B) float64 image ----------------------------------------
+// normalize_channel clips every channel to its [1st, 99th] percentile and scales to [0, 1]; prepare_image transposes to (B, A) and
+// pads in front to the network's extents.  The percentiles are np.percentile's: order statistics k, k + 1 of the channel plus
+// numpy's lerp.  They come from a most-significant-digit radix select over sortable 64-bit keys (eight byte-wide passes, both
+// ranks of every channel in one launch; the same scheme as tip_select.hip) -- no sort -- and never leave the device: the
+// normalise / transpose / pad pass reads them from memory.
+constexpr int PREP_MAXC = 8;
+struct PrepState {                      // per (channel, which percentile): [c][0] = the 1st, [c][1] = the 99th
+    unsigned int hist[PREP_MAXC][2][256];
+    unsigned long long prefix[PREP_MAXC][2], above[PREP_MAXC][2];
+    long long rank[PREP_MAXC][2], room[PREP_MAXC][2];
+    double per[PREP_MAXC][2], clipv[PREP_MAXC][2];      // percentile values; the values written over the clipped pixels
+};
+
+__device__ __forceinline__ unsigned long long prep_enc(double d)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(d + 0.0);   // (-0.0 sorts with +0.0, like numpy's <)
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double prep_dec(unsigned long long e)
+{
+    unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffULL) : ~e;
+    return __longlong_as_double((long long)b);
+}
+
+__global__ void __launch_bounds__(64) k_prep_reset(PrepState *st, int C, long long r1, long long r99)
+{
+    const int t = threadIdx.x;
+    for (int i = t; i < C * 2 * 256; i += 64) (&st->hist[0][0][0])[i] = 0;
+    if (t < C * 2) {
+        const int c = t >> 1, w = t & 1;
+        st->prefix[c][w] = 0; st->above[c][w] = ~0ULL; st->room[c][w] = 0;
+        st->rank[c][w] = w ? r99 : r1;
+    }
+}
+
+// one digit of both selects of channel blockIdx.y; the plane is dense (n consecutive doubles from img + c * cstride)
+__global__ void __launch_bounds__(256) k_prep_hist(const double *__restrict__ img, long cstride, long n, PrepState *st, int shift)
+{
+    __shared__ unsigned int sh[2][256];
+    const int c = blockIdx.y;
+    sh[0][threadIdx.x] = 0; sh[1][threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long p0 = st->prefix[c][0], p1 = st->prefix[c][1];
+    const double *src = img + (long)c * cstride;
+    const long i0 = (long)blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long i = i0 + u * 256;
+        if (i < n) {
+            const unsigned long long key = prep_enc(src[i]);
+            const int bin = (int)((key >> shift) & 255ULL);
+            const bool m0 = shift == 56 || (key >> (shift + 8)) == (p0 >> (shift + 8));
+            const bool m1 = shift == 56 || (key >> (shift + 8)) == (p1 >> (shift + 8));
+            if (m0) atomicAdd(&sh[0][bin], 1u);
+            if (m1) atomicAdd(&sh[1][bin], 1u);
+        }
+    }
+    __syncthreads();
+    if (sh[0][threadIdx.x]) atomicAdd(&st->hist[c][0][threadIdx.x], sh[0][threadIdx.x]);
+    if (sh[1][threadIdx.x]) atomicAdd(&st->hist[c][1][threadIdx.x], sh[1][threadIdx.x]);
+}
+
+// the bin holding the rank: prefix gets the digit, rank becomes the rank inside the bin; on the last digit `room` = how many more
+// copies of the selected key follow (so that rank + 1 can be answered)
+__global__ void __launch_bounds__(64) k_prep_pick(PrepState *st, int C, int shift)
+{
+    const int t = threadIdx.x;
+    if (t >= C * 2) return;
+    const int c = t >> 1, w = t & 1;
+    unsigned int *h = st->hist[c][w];
+    const long long r = st->rank[c][w];
+    long long cum = 0;
+    int pick = 255;
+    for (int b = 0; b < 256; ++b) {
+        const long long cnt = h[b];
+        if (cum + cnt > r) { pick = b; break; }
+        cum += cnt;
+    }
+    if (shift == 0) st->room[c][w] = (long long)h[pick] - (r - cum) - 1;
+    st->prefix[c][w] |= (unsigned long long)pick << shift;
+    st->rank[c][w] = r - cum;
+    for (int b = 0; b < 256; ++b) h[b] = 0;
+}
+
+// smallest key strictly above each selected one
+__global__ void __launch_bounds__(256) k_prep_next(const double *__restrict__ img, long cstride, long n, PrepState *st)
+{
+    const int c = blockIdx.y;
+    const unsigned long long p0 = st->prefix[c][0], p1 = st->prefix[c][1];
+    unsigned long long a0 = ~0ULL, a1 = ~0ULL;
+    const double *src = img + (long)c * cstride;
+    for (long i = (long)blockIdx.x * 2048 + threadIdx.x, e = min(n, ((long)blockIdx.x + 1) * 2048); i < e; i += 256) {
+        const unsigned long long key = prep_enc(src[i]);
+        if (key > p0 && key < a0) a0 = key;
+        if (key > p1 && key < a1) a1 = key;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o0 = __shfl_xor(a0, d, 64), o1 = __shfl_xor(a1, d, 64);
+        a0 = o0 < a0 ? o0 : a0;
+        a1 = o1 < a1 ? o1 : a1;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a0 != ~0ULL) atomicMin(&st->above[c][0], a0);
+        if (a1 != ~0ULL) atomicMin(&st->above[c][1], a1);
+    }
+}
+
+// np.percentile's 'linear' lerp (numpy/lib/function_base.py _lerp: lo + diff * g, and hi - diff * (1 - g) from g >= 0.5) and the
+// values normalize_channel writes over the clipped pixels, which take the INPUT's dtype (pl.py:26-27 assign into a copy of the
+// image): kind 0 = float64 (as is), 1 = float32 (rounded), 2 = integer (truncated)
+__global__ void __launch_bounds__(64) k_prep_finish(PrepState *st, int C, double g1, double g99, int kind)
+{
+    const int t = threadIdx.x;
+    if (t >= C * 2) return;
+    const int c = t >> 1, w = t & 1;
+    const double lo = prep_dec(st->prefix[c][w]);
+    const double hi = st->room[c][w] > 0 ? lo : (st->above[c][w] == ~0ULL ? lo : prep_dec(st->above[c][w]));
+    const double g = w ? g99 : g1;
+    const double diff = hi - lo;
+    double res = lo + diff * g;
+    if (g >= 0.5) res = hi - diff * (1.0 - g);
+    st->per[c][w] = res;
+    st->clipv[c][w] = kind == 2 ? trunc(res) : (kind == 1 ? (double)(float)res : res);
+}
+
+// out[c][pb + b][pa + a] = normalised in[c][a][b]; A_CONTIG: the input's a index has unit stride (threads run along a on both
+// sides), else its b index has (a 32 x 32 tile turns through LDS)
+template <bool A_CONTIG>
+__global__ void __launch_bounds__(256) k_prep_normalize(const double *__restrict__ img, long cstride, long sa, long sb, int A, int B,
+                                                        const PrepState *__restrict__ st, int single, float *__restrict__ out, int Ap,
+                                                        int Bp, int pa, int pb)
+{
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z, a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const double per1 = st->per[c][0], per99 = st->per[c][1], lo = st->clipv[c][0], hi = st->clipv[c][1];
+    const double den = per99 - per1;
+    const float per1f = (float)per1, denf = (float)den;
+    const double *src = img + (long)c * cstride;
+    float *dst = out + (long)c * Ap * Bp;
+    auto norm = [&](double v) -> float {
+        double cl = v > per99 ? hi : v;
+        cl = v < per1 ? lo : cl;
+        if (single) return ((float)cl - per1f) / denf;       // numpy 1.x: float32 array (op) float64 scalar stays float32
+        return (float)((cl - per1) / den);
+    };
+    if (A_CONTIG) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = a0 + tx, b = b0 + ty + k * 8;
+            if (a < A && b < B) dst[(long)(pb + b) * Ap + pa + a] = norm(src[(long)a * sa + (long)b * sb]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = a0 + ty + k * 8, b = b0 + tx;
+            if (a < A && b < B) tile[ty + k * 8][tx] = norm(src[(long)a * sa + (long)b * sb]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = a0 + tx, b = b0 + ty + k * 8;
+            if (a < A && b < B) dst[(long)(pb + b) * Ap + pa + a] = tile[tx][ty + k * 8];
+        }
+    }
+}
+
 }  // namespace tip
 
 using namespace tip;
@@ -147,11 +317,57 @@ static int unet_launch_check(const char *what)
     return TIP_OK;
 }
 
+// pl.py:90-122 + 21-29 for a device-resident image: img = (c, a, b) float64 with element strides (cstride, sa, sb), every channel
+// plane dense (sa == 1 && sb == a, or sb == 1 && sa == b); kind = dtype of the ORIGINAL image (0 float64, 1 float32, 2 integer:
+// normalize_channel's clip values take it).  out = (c, bp, ap) float32, zero-filled in front: out[c][bp - b + j][ap - a + i] =
+// normalised img[c][i][j].  Launches on `stream` (torch's current stream: the buffers are torch tensors) and returns at once.
+int tip_unet_prepare_f64_dev(const double *img, int c, int a, int b, long cstride, long sa, long sb, int kind, float *out, int ap, int bp,
+                             void *stream)
+{
+    Ctx &cx = ctx();
+    if (!cx.stream) return TIP_ERR_HIP;
+    if (!img || !out || c < 1 || c > PREP_MAXC || a < 1 || b < 1 || ap < a || bp < b || kind < 0 || kind > 2)
+        return fail(TIP_ERR_ARG, "tip_unet_prepare_f64_dev: bad arguments");
+    const bool a_contig = sa == 1 && sb == a, b_contig = sb == 1 && sa == b;
+    if (!a_contig && !b_contig) return fail(TIP_ERR_UNSUPPORTED, "tip_unet_prepare_f64_dev: every channel plane must be dense");
+    if (!cx.prep_ws) TIP_HIP(hipMalloc(&cx.prep_ws, sizeof(PrepState)));
+    PrepState *st = (PrepState *)cx.prep_ws;
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)a * b;
+    // numpy: virtual index (n - 1) q, previous = floor, gamma = the fraction (function_base.py _quantile / _lerp)
+    auto split = [&](double q, long long &prev, double &g) {
+        const double virt = (double)(n - 1) * q;
+        prev = (long long)floor(virt);
+        g = virt - (double)prev;
+        if (prev < 0) prev = 0;
+        if (prev > n - 1) prev = n - 1;
+    };
+    long long r1, r99;
+    double g1, g99;
+    split(1.0 / 100.0, r1, g1);
+    split(99.0 / 100.0, r99, g99);
+    hipLaunchKernelGGL(k_prep_reset, dim3(1), dim3(64), 0, s, st, c, r1, r99);
+    const dim3 hgrid((unsigned)cdiv(n, 2048), (unsigned)c);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_prep_hist, hgrid, dim3(256), 0, s, img, cstride, n, st, shift);
+        hipLaunchKernelGGL(k_prep_pick, dim3(1), dim3(64), 0, s, st, c, shift);
+    }
+    hipLaunchKernelGGL(k_prep_next, hgrid, dim3(256), 0, s, img, cstride, n, st);
+    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(64), 0, s, st, c, g1, g99, kind);
+    if (ap != a || bp != b) TIP_HIP(hipMemsetAsync(out, 0, (size_t)c * ap * bp * sizeof(float), s));
+    const dim3 ngrid((unsigned)cdiv(a, 32), (unsigned)cdiv(b, 32), (unsigned)c);
+    if (a_contig)
+        hipLaunchKernelGGL(k_prep_normalize<true>, ngrid, dim3(256), 0, s, img, cstride, sa, sb, a, b, (const PrepState *)st, kind == 1 ? 1 : 0, out, ap, bp, ap - a, bp - b);
+    else
+        hipLaunchKernelGGL(k_prep_normalize<false>, ngrid, dim3(256), 0, s, img, cstride, sa, sb, a, b, (const PrepState *)st, kind == 1 ? 1 : 0, out, ap, bp, ap - a, bp - b);
+    return unet_launch_check("unet_prepare");
+}
+
 int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!d || !d->in0 || !d->weights || !d->bias || !d->out) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: null pointer");
+    if (!d || !d->in0 || !d->weights || !d->bias || (!d->out && !d->head_out)) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: null pointer");
     if (d->planes != 2 && d->planes != 3) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: planes must be 2 or 3");
     if (d->h < 8 || d->w < UC_TW || d->h % 8 || d->w % UC_TW)
         return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: the grid %dx%d is not a multiple of the 8x%d pixel tile", d->h, d->w, UC_TW);
@@ -177,11 +393,19 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     }
     p.zeros = (const uint16_t *)c.zero_page;
     p.pool_out = (uint16_t *)d->pool_out;
+    p.head_w = d->head_w; p.head_b = d->head_b; p.head_out = d->head_out;
+    if (d->head_out && (!d->head_w || !d->head_b || d->cout != UC_BN || !d->scale || d->pool_out || d->sy != 1 || d->sx != 1 || d->oy != 0 || d->ox != 0 ||
+                        d->out_h != d->h || d->out_w != d->w))
+        return fail(TIP_ERR_ARG, "tip_unet_conv_dev: the fused head needs a 128-channel Conv2D + BatchNorm layer with the plain output mapping");
     if (d->pool_out && (d->sy != 1 || d->sx != 1 || d->oy != 0 || d->ox != 0 || d->out_h != d->h || d->out_w != d->w))
         return fail(TIP_ERR_ARG, "tip_unet_conv_dev: pool_out needs the plain output mapping");
     // 16-row tiles (one 512-thread workgroup per CU) where the grid allows: half the weight copies per MFMA, and LDS for five
     // weight buffers (copies four steps ahead) when the stencil has >= 4 taps; two pieces only (LDS)
-    const int th = (d->planes == 2 && d->h % 16 == 0 && !tuning().unet_tile8) ? 16 : 8;
+    const int t8 = tuning().unet_tile8;
+    // (measured per layer at 2048^2: the short K loops of the 128-channel 3x3 layers gain 1-3 % from two workgroups per CU -- one's
+    // epilogue behind the other's products -- every other layer is faster with the shared weight tile of the 16-row workgroup)
+    const bool want8 = t8 == 1 || (t8 < 0 && d->ntaps == 9 && d->c0 + d->c1 <= 128);
+    const int th = (d->planes == 2 && d->h % 16 == 0 && !want8) ? 16 : 8;
     const int dist = (th == 16 && d->ntaps >= 4) ? 4 : 2;
     const int da = (th == 16 && d->ntaps <= 2) ? 2 : 1;       // one- and two-tap stencils: activation tiles two chunks ahead
     const int threads = th * 32, hp = UC_HW * (th + 2);
@@ -209,9 +433,9 @@ int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, con
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || ((long)h * w) % 16 || (planes != 2 && planes != 3))
-        return fail(TIP_ERR_ARG, "tip_unet_conv_first_dev: bad arguments");
-    const dim3 grid((unsigned)((long)h * w / 16));
+    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || w % FIRST_RUN || ((long)h * w) % FIRST_PIX || (planes != 2 && planes != 3))
+        return fail(TIP_ERR_ARG, "tip_unet_conv_first_dev: bad arguments (w must be a multiple of 32, h * w of 256)");
+    const dim3 grid((unsigned)((long)h * w / FIRST_PIX));
     hipStream_t s = (hipStream_t)stream;
     if (planes == 2) hipLaunchKernelGGL(k_unet_conv_first<2>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
     else hipLaunchKernelGGL(k_unet_conv_first<3>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);

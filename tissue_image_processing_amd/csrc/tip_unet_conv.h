@@ -34,6 +34,7 @@ namespace tip {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int UC_TW = 32;                     // pixel tile: TH rows (8 or 16: template parameter) x 32 columns
 constexpr int UC_BN = 128;                    // output channels per workgroup
@@ -52,6 +53,8 @@ struct ConvParams {
     uint16_t *out;                 // [plane][outH][outW][cout]
     int outH, outW, sy, sx, oy, ox;       // output pixel of input-grid pixel (y, x): (y * sy + oy, x * sx + ox)
     const uint16_t *zeros;         // >= 16 bytes of zeros on the device: the source of halo pixels outside the image
+    const float *head_w, *head_b;  // nullptr, or the network's head fused into this layer's epilogue (cout == 128, plain output mapping):
+    float *head_out;               //   Conv2D(128 -> 2, 1x1) weights [2][128], bias [2] -> softmax -> float32 (2, H, W); `out` is then not written
     uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
@@ -61,6 +64,22 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float v)
     return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;     // round to nearest even (finite values)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+// max(v, 0) on the bit pattern (a negative float is a negative integer): one instruction, no NaN canonicalisation in front
+__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+// plain v_max_f32 (fmaxf() quiets signalling NaNs first: two more instructions per call)
+__device__ __forceinline__ float fmax_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(v, v of the neighbouring lane (lane ^ 1))
+__device__ __forceinline__ float fmax_pair(float v)
+{
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
@@ -151,6 +170,10 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             __builtin_amdgcn_global_load_lds(src + u * (UC_THREADS / 256) * (UC_BN * UC_KC), dst + u * UC_THREADS * 16, 16, 0, 0);
     };
 
+    // Accumulators: D = W^T X^T -- the WEIGHT fragment is the matrix core's A operand, so a lane holds ONE pixel (column lane & 31)
+    // and sixteen output channels per 32-channel block: register i of half-wave hf is row 8 (i >> 2) + 4 hf + (i & 3), and the packed
+    // weight tile stores channel 16 hf + i in that row (host: _split_pack), i.e. the lane's sixteen registers are the sixteen ADJACENT
+    // channels n * 32 + 16 hf + i of its pixel.
     f32x16 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -170,42 +193,50 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     int step = 0;
     int nc = D / p.ntaps, nt = D % p.ntaps;                  // (chunk, tap) of step + D
     int buf0 = 0, buf2 = D;                                  // weight buffers of steps s and s + D (no division in the loop)
+    bf16x8 fa[2][NPL], fb[4][NPL];
+    // fragments of step (chunk, tap), the operands of the first product group first
+    auto load_frags = [&](int chunk, int tap) {
+        const unsigned char *abuf = sA + (chunk % (DA + 1)) * A_BYTES;
+        const unsigned char *bbuf = sB + buf0 * B_BYTES;
+        const int dy = p.dy[tap], dx = p.dx[tap];
+        int aslot[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
+            aslot[m] = px * 2 + (h ^ ((px >> 3) & 1));
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                fa[m][NPL - 1 - k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + ((NPL - 1 - k) * UC_HP * 2 + aslot[m]) * 16));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                fb[n][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (k * 256 + n * 64 + b_row) * 16));
+        }
+    };
+    // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
+#define UC_PRODUCT(PA, PB)                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][PB], fa[m][PA], acc[m][n], 0, 0, 0);
+    auto products = [&]() {
+        __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
+        if constexpr (NPL == 3) { UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2) }
+        UC_PRODUCT(1, 0)
+        UC_PRODUCT(0, 1)
+        UC_PRODUCT(0, 0)
+        __builtin_amdgcn_s_setprio(0);
+    };
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
-            // copies: the next chunk's activations at the chunk's first tap, the weights of step + 2
+            // copies: the next chunk's activations at the chunk's first tap, the weights of step + D
             const bool issue_a = tap == 0 && chunk + DA < nchunks;
             const bool issue_b = step + D < nsteps;
             if (issue_a) copy_a(chunk + DA, (chunk + DA) % (DA + 1));
             if (issue_b) copy_b(nc, nt, buf2);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
-            const unsigned char *abuf = sA + (chunk % (DA + 1)) * A_BYTES;
-            const unsigned char *bbuf = sB + buf0 * B_BYTES;
-            const int dy = p.dy[tap], dx = p.dx[tap];
-            bf16x8 fa[2][NPL], fb[4][NPL];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
-                const int slot = px * 2 + (h ^ ((px >> 3) & 1));
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + (pl * UC_HP * 2 + slot) * 16));
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16));
-            // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
-#define UC_PRODUCT(PA, PB)                                                                                      \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[n][PB], acc[m][n], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
-            if constexpr (NPL == 3) { UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2) }
-            UC_PRODUCT(1, 0)
-            UC_PRODUCT(0, 1)
-            UC_PRODUCT(0, 0)
-            __builtin_amdgcn_s_setprio(0);
-#undef UC_PRODUCT
+            load_frags(chunk, tap);
+            products();
             // Before the barrier the weights of step + 1 must have landed (issued one step ago, before everything issued in
             // this step) and, when the next step opens a new chunk, its activations too.  Issue order inside a step is
             // activations first, weights second, so "at most B_PER outstanding" also covers the activations.
@@ -235,168 +266,257 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             buf2 = buf2 + 1 == UC_NBBUF ? 0 : buf2 + 1;
         }
     }
+#undef UC_PRODUCT
 
-    // ---- epilogue: float32 bias [-> ReLU -> scale, shift], split, store through LDS ------------------------------------------
-    // A lane holds ONE output channel of 16 pixels per accumulator tile: stored from the registers, a wave's store touches 64-byte
-    // pieces of many rows, and with the stores taken out the whole network ran 17 % faster -- the epilogue was bound by the store
-    // path, not by HBM.  So a tile row goes through the (now idle) LDS: v_cvt_pk_bf16_f32 rounds two neighbouring pixels of the
-    // lane's channel into one word (nearest even; the remainder stays in the accumulator for the next piece), adjacent lanes
-    // (channels r, r ^ 1) trade words through a DPP swap and a byte permute leaves every lane with two adjacent channels of ONE
-    // pixel, which it writes to a [32 pixels][128 channels] image (320-byte rows: the even and odd lanes of a half-wave hit
-    // disjoint banks); the image is read back in rows and leaves as 8 bytes per lane, 256 contiguous bytes per pixel.
-    // One (tile row, piece) at a time, 10 KB per wave.  With pool_out set (Conv2D followed by MaxPool2D(2), pl.py:42-43) the 2 x 2
-    // window of a pooled pixel -- rows 2w, 2w + 1 of the wave, registers i, i + 1 -- lies in one lane: the pooled map goes out the
-    // same way first (max-then-split equals the pooled split map: the pieces are a monotone function of the value).
-    constexpr int EP_ROW = 320, EP_BYTES = (NPL * 16 > 32 ? NPL * 16 : 32) * EP_ROW;
+    // ---- epilogue: bias [-> ReLU -> scale, shift], split, store through LDS -----------------------------------------------------------
+    // A lane holds 16 adjacent channels of one pixel per 32-channel block: ReLU and the
+    // BatchNorm scale / shift (one fused multiply-add, packed two channels per instruction) take the per-channel constants as
+    // 16-byte loads, v_cvt_pk_bf16_f32 rounds two adjacent channels into one word (nearest even; the remainder -- a packed subtract --
+    // stays in the accumulator for the next piece), and eight channels leave as ONE 16-byte LDS write: no lane exchange.  Stored
+    // straight from the registers a wave's store would touch 32-byte pieces of 32 pixel rows (the store path, not HBM, bound that
+    // variant), so a tile row goes through the (now idle) LDS as a [32 pixels][128 channels] image (272-byte rows: a 16-lane
+    // group's 16-byte accesses hit 16 different bank quads) and is read back four whole pixels -- 4 x 256 contiguous bytes -- per
+    // instruction.  One (tile row, piece) at a time, 8.5 KB per wave.  With pool_out set (Conv2D followed by MaxPool2D(2),
+    // pl.py:42-43) the 2 x 2 window of a pooled pixel is the lane's two tile rows x the neighbouring lane (one DPP max): the pooled
+    // map goes out the same way first (max-then-split equals the pooled split map: the pieces are a monotone function of the value).
+    // No barrier in front: every wave reads its last fragments and sees its last copies land BEFORE the final step's barrier, so a
+    // wave that is past that barrier may overwrite the tile buffers.
+    constexpr int EP_ROW = 272, EP_BYTES = 32 * EP_ROW;
     static_assert(UC_THREADS / 64 * EP_BYTES <= (DA + 1) * A_BYTES + UC_NBBUF * B_BYTES, "the staging images fit the tile buffers");
-    __syncthreads();                                  // every wave has left the main loop: the tile buffers are free
-    int re = r, he = h;
-    asm volatile("" : "+v"(re), "+v"(he));            // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
+    int pxl = lane & 31, hf = lane >> 5;
+    asm volatile("" : "+v"(pxl), "+v"(hf));           // (opaque: nothing of the epilogue's addressing is hoisted into the main loop's registers)
     unsigned char *ep = smem + wave * EP_BYTES;
-    const bool odd = re & 1;
-    const unsigned perm_sel = odd ? 0x03020706u : 0x05040100u;       // even lanes: (own a, neighbour's a); odd: (neighbour's b, own b)
-    auto swap_lanes = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
-    // rounds (a, b) to the next piece, keeps the remainders when more pieces follow, returns this lane's word of the image
-    auto piece_word = [&](float &a, float &b, bool more) -> unsigned {
-        bf16x2 hv;
-        hv[0] = (__bf16)a;
-        hv[1] = (__bf16)b;
-        const unsigned mine = __builtin_bit_cast(unsigned, hv);
-        if (more) {
-            a -= __uint_as_float(mine << 16);
-            b -= __uint_as_float(mine & 0xffff0000u);
-        }
-        return __builtin_amdgcn_perm(swap_lanes(mine), mine, perm_sel);
-    };
-    const int lrow = lane >> 5, lcol = lane & 31;     // read-back: half-wave = one image row, 8 bytes per lane
-    const long out_plane = (long)p.outH * p.outW * p.cout;
+    {
+        const float *bip = p.bias + nblk * UC_BN + 16 * hf;
+        const float *scp = p.scale + nblk * UC_BN + 16 * hf, *shp = p.shift + nblk * UC_BN + 16 * hf;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int co = nblk * UC_BN + n * 32 + re;
-        const float b = p.bias[co];
-        const float sc = p.scale ? p.scale[co] : 1.f, sh = p.scale ? p.shift[co] : 0.f;
+        for (int n = 0; n < 4; ++n) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bip + n * 32 + q * 4);
+                const f32x2 b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
+                if (p.scale) {
+                    const float4 s4 = *reinterpret_cast<const float4 *>(scp + n * 32 + q * 4), t4 = *reinterpret_cast<const float4 *>(shp + n * 32 + q * 4);
+                    const f32x2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = acc[m][n][i] + b;
-                if (p.scale) { v = v > 0.f ? v : 0.f; v = v * sc + sh; }
-                acc[m][n][i] = v;
+                    for (int m = 0; m < 2; ++m) {
+                        f32x2 v01 = f32x2{acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1]} + b01;
+                        f32x2 v23 = f32x2{acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3]} + b23;
+                        v01 = __builtin_elementwise_fma(f32x2{relu_bits(v01[0]), relu_bits(v01[1])}, s01, t01);
+                        v23 = __builtin_elementwise_fma(f32x2{relu_bits(v23[0]), relu_bits(v23[1])}, s23, t23);
+                        acc[m][n][q * 4 + 0] = v01[0]; acc[m][n][q * 4 + 1] = v01[1];
+                        acc[m][n][q * 4 + 2] = v23[0]; acc[m][n][q * 4 + 3] = v23[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const f32x2 v01 = f32x2{acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1]} + b01;
+                        const f32x2 v23 = f32x2{acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3]} + b23;
+                        acc[m][n][q * 4 + 0] = v01[0]; acc[m][n][q * 4 + 1] = v01[1];
+                        acc[m][n][q * 4 + 2] = v23[0]; acc[m][n][q * 4 + 3] = v23[1];
+                    }
+                }
             }
+            asm volatile("" ::: "memory");       // (one block's constants at a time: the loads are not all hoisted in front)
+        }
     }
-    if (p.pool_out) {
-        const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
+    if (p.head_out) {
+        // The network's head (pl.py:69: Conv2D(2, 1) + softmax over the two classes) on the float32 values in the registers: a lane
+        // holds 64 of its two pixels' 128 channels, the other 64 sit in lane ^ 32.  The layer's own output has no other reader and
+        // is not stored (2.1 GB less to write and to read back at 2048^2, and the head sees unsplit float32 values).
+        float z[2][2] = {{0.f, 0.f}, {0.f, 0.f}};       // [tile row m][class]
+        const float *hw0 = p.head_w + 16 * hf, *hw1 = p.head_w + UC_BN + 16 * hf;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) {      // registers i .. i + 3: pixels x .. x + 3 -> pooled pixels x / 2, x / 2 + 1
-                float q0 = fmaxf(fmaxf(acc[0][n][i], acc[0][n][i + 1]), fmaxf(acc[1][n][i], acc[1][n][i + 1]));
-                float q1 = fmaxf(fmaxf(acc[0][n][i + 2], acc[0][n][i + 3]), fmaxf(acc[1][n][i + 2], acc[1][n][i + 3]));
-                const int row = 4 * (i >> 2) + 2 * he + (odd ? 1 : 0);
+            for (int q = 0; q < 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(hw0 + n * 32 + q * 4), b4 = *reinterpret_cast<const float4 *>(hw1 + n * 32 + q * 4);
+                const float wa[4] = {a4.x, a4.y, a4.z, a4.w}, wb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    *reinterpret_cast<unsigned *>(ep + (pl * 16 + row) * EP_ROW + ((n * 32 + re) >> 1) * 4) = piece_word(q0, q1, pl + 1 < NPL);
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z[m][0] = __builtin_fmaf(acc[m][n][q * 4 + j], wa[j], z[m][0]);
+                        z[m][1] = __builtin_fmaf(acc[m][n][q * 4 + j], wb[j], z[m][1]);
+                    }
             }
-        uint16_t *prow = p.pool_out + ((long)(ty0 / 2 + wave) * (p.outW / 2) + tx0 / 2) * p.cout + nblk * UC_BN + lcol * 4;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 2 + lrow;
-                *reinterpret_cast<uint2 *>(prow + pl * pool_plane + (long)row * p.cout) =
-                    *reinterpret_cast<const uint2 *>(ep + (pl * 16 + row) * EP_ROW + lcol * 8);
+            for (int c = 0; c < 2; ++c) z[m][c] += __shfl_xor(z[m][c], 32, 64);
+        const float z0 = (hf ? z[1][0] : z[0][0]) + p.head_b[0], z1 = (hf ? z[1][1] : z[0][1]) + p.head_b[1];     // half-wave hf: tile row hf
+        const float zm = z0 > z1 ? z0 : z1;
+        const float e0 = __expf(z0 - zm), e1 = __expf(z1 - zm);
+        const float es = e0 + e1;
+        const long o = (long)(ty0 + wave * 2 + hf) * p.W + tx0 + pxl;
+        p.head_out[o] = e0 / es;
+        p.head_out[(long)p.H * p.W + o] = e1 / es;
+        return;
+    }
+    // rounds (a, b) to the next piece and keeps the remainders when more pieces follow; returns the packed word
+    auto piece_word = [](float &a, float &b, bool more) -> unsigned {
+        bf16x2 hv;
+        hv[0] = (__bf16)a;
+        hv[1] = (__bf16)b;
+        const unsigned w = __builtin_bit_cast(unsigned, hv);
+        if (more) {
+            const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+            a = r[0];
+            b = r[1];
+        }
+        return w;
+    };
+    const int rd_row = lane >> 4, rd_col = (lane & 15) * 16;       // read-back: 16 lanes = one pixel's 256 bytes
+    const long out_plane = (long)p.outH * p.outW * p.cout;
+    if (p.pool_out) {
+        const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
+        const bool oddp = pxl & 1;
+        float q8[4][8];            // the lane's half of the pooled pixel's channels: even lanes 0..7, odd lanes 8..15 of every block
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = fmax_pair(fmax_raw(acc[0][n][i], acc[1][n][i]));
+                if (i < 8) q8[n][i] = v; else if (oddp) q8[n][i - 8] = v;
             }
+        uint16_t *prow = p.pool_out + ((long)(ty0 / 2 + wave) * (p.outW / 2) + tx0 / 2) * p.cout + nblk * UC_BN + (lane & 15) * 8;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                uint4 w;
+                w.x = piece_word(q8[n][0], q8[n][1], pl + 1 < NPL);
+                w.y = piece_word(q8[n][2], q8[n][3], pl + 1 < NPL);
+                w.z = piece_word(q8[n][4], q8[n][5], pl + 1 < NPL);
+                w.w = piece_word(q8[n][6], q8[n][7], pl + 1 < NPL);
+                *reinterpret_cast<uint4 *>(ep + (pxl >> 1) * EP_ROW + (n * 32 + 16 * hf + (oddp ? 8 : 0)) * 2) = w;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + rd_row;
+                *reinterpret_cast<uint4 *>(prow + pl * pool_plane + (long)row * p.cout) = *reinterpret_cast<const uint4 *>(ep + row * EP_ROW + rd_col);
+            }
+        }
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int y = ty0 + wave * 2 + m;
-        uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + ((long)tx0 * p.sx + p.ox)) * p.cout + nblk * UC_BN + lcol * 4;
+        uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + ((long)tx0 * p.sx + p.ox)) * p.cout + nblk * UC_BN + (lane & 15) * 8;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * he + (odd ? 1 : 0);
-                    float va = acc[m][n][i], vb = acc[m][n][i + 1];        // (vector elements do not bind to references)
-                    *reinterpret_cast<unsigned *>(ep + row * EP_ROW + ((n * 32 + re) >> 1) * 4) = piece_word(va, vb, pl + 1 < NPL);
-                    acc[m][n][i] = va;
-                    acc[m][n][i + 1] = vb;
+                for (int q = 0; q < 2; ++q) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = acc[m][n][q * 8 + j];      // (vector elements do not bind to references)
+                    uint4 w;
+                    w.x = piece_word(v[0], v[1], pl + 1 < NPL);
+                    w.y = piece_word(v[2], v[3], pl + 1 < NPL);
+                    w.z = piece_word(v[4], v[5], pl + 1 < NPL);
+                    w.w = piece_word(v[6], v[7], pl + 1 < NPL);
+                    if (pl + 1 < NPL) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[m][n][q * 8 + j] = v[j];
+                    }
+                    *reinterpret_cast<uint4 *>(ep + pxl * EP_ROW + (n * 32 + 16 * hf + 8 * q) * 2) = w;
                 }
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 2 + lrow;
-                *reinterpret_cast<uint2 *>(orow + pl * out_plane + (long)row * p.sx * p.cout) = *reinterpret_cast<const uint2 *>(ep + row * EP_ROW + lcol * 8);
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + rd_row;
+                *reinterpret_cast<uint4 *>(orow + pl * out_plane + (long)row * p.sx * p.cout) = *reinterpret_cast<const uint4 *>(ep + row * EP_ROW + rd_col);
             }
         }
     }
 }
 
 // ---- first layer: Conv2D(2 -> 128, 3x3) on the float32 (2, H, W) network input --------------------------------------------------
-// K = 18: nothing for the matrix cores -- the layer is its 2.1 GB of output.  Exact float32 FMAs; a thread owns 8 adjacent output
-// channels of one pixel, sixteen threads a pixel, so a wave's stores are 1 KB contiguous per piece (four pixels x 256 bytes) and
-// the split of two adjacent channels is one v_cvt_pk_bf16_f32 (no lane exchange).  Weights [18][128] in LDS, read as float4.
+// K = 18: nothing for the matrix cores -- the layer is its 2.1 GB of output.  Exact float32 FMAs; a thread owns 4 adjacent output
+// channels, keeps their 18 x 4 weights in registers and walks a run of FIRST_RUN consecutive pixels of one row with the 3 x 3 x 2
+// input window sliding through registers (six loads and no address arithmetic per pixel: with per-pixel tap addressing the kernel
+// was bound by its own index arithmetic, 210 vector instructions per pixel and thread, 0.8 ms against 0.45 ms for the stores
+// alone).  Thirty-two threads share a pixel, so the split of two adjacent channels is one v_cvt_pk_bf16_f32 (no lane exchange) and
+// a pixel's 256 bytes per piece leave in one piece.
+constexpr int FIRST_RUN = 32;       // consecutive pixels per 32-thread slot; a 256-thread block covers 8 runs = 256 pixels of a row
+constexpr int FIRST_PIX = 8 * FIRST_RUN;
 template <int NPL>
 __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict__ in, int H, int W, const float *__restrict__ wgt /* [9][2][128] */,
                                                          const float *__restrict__ bias, const float *__restrict__ scale,
                                                          const float *__restrict__ shift, uint16_t *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float sw[18 * 128];
-    for (int i = threadIdx.x; i < 18 * 128; i += 256) sw[i] = wgt[i];
-    __syncthreads();
-    const int cg = threadIdx.x & 15;
-    const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
-    float v[18];
+    const int cg = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    float4 w4[18];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const long o = (long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
-        const float a = in[o], b = in[(long)H * W + o];
-        v[2 * t] = inside ? a : 0.f;
-        v[2 * t + 1] = inside ? b : 0.f;
+    for (int k = 0; k < 18; ++k) w4[k] = *reinterpret_cast<const float4 *>(wgt + k * 128 + cg * 4);
+    const float4 bb = *reinterpret_cast<const float4 *>(bias + cg * 4);
+    const float4 ss = *reinterpret_cast<const float4 *>(scale + cg * 4);
+    const float4 tt = *reinterpret_cast<const float4 *>(shift + cg * 4);
+    const long plane = (long)H * W * 128, chan = (long)H * W;
+    const long pix0 = (long)blockIdx.x * FIRST_PIX + slot * FIRST_RUN;        // (W % FIRST_RUN == 0: a run stays inside one row)
+    const int y = (int)(pix0 / W), x0 = (int)(pix0 - (long)y * W);
+    // the three input rows (clamped addresses, zero where the row lies outside the image: 'same' padding)
+    const float *rowp[3];
+    bool rowin[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        rowin[dy] = yy >= 0 && yy < H;
+        rowp[dy] = in + (long)min(max(yy, 0), H - 1) * W;
     }
-    float a[8];
+    auto column = [&](int xx, float (&c)[3][2]) {          // input column xx of the window: [row][channel]
+        const bool xin = xx >= 0 && xx < W;
+        const int xc = min(max(xx, 0), W - 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const float a = rowp[dy][xc], b = rowp[dy][chan + xc];
+            c[dy][0] = xin && rowin[dy] ? a : 0.f;
+            c[dy][1] = xin && rowin[dy] ? b : 0.f;
+        }
+    };
+    float win[3][3][2];          // [column slot][row][channel]; slot (it + k) % 3 holds column x - 1 + k
+    column(x0 - 1, win[0]);
+    column(x0, win[1]);
+    uint16_t *dst = out + pix0 * 128 + cg * 4;
+    for (int it0 = 0; it0 < FIRST_RUN; it0 += 3) {
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
-        const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * 128 + cg * 8), w1 = *reinterpret_cast<const float4 *>(sw + k * 128 + cg * 8 + 4);
-        a[0] = __builtin_fmaf(v[k], w0.x, a[0]); a[1] = __builtin_fmaf(v[k], w0.y, a[1]);
-        a[2] = __builtin_fmaf(v[k], w0.z, a[2]); a[3] = __builtin_fmaf(v[k], w0.w, a[3]);
-        a[4] = __builtin_fmaf(v[k], w1.x, a[4]); a[5] = __builtin_fmaf(v[k], w1.y, a[5]);
-        a[6] = __builtin_fmaf(v[k], w1.z, a[6]); a[7] = __builtin_fmaf(v[k], w1.w, a[7]);
-    }
-    const float4 b0 = *reinterpret_cast<const float4 *>(bias + cg * 8), b1 = *reinterpret_cast<const float4 *>(bias + cg * 8 + 4);
-    const float4 s0 = *reinterpret_cast<const float4 *>(scale + cg * 8), s1 = *reinterpret_cast<const float4 *>(scale + cg * 8 + 4);
-    const float4 t0 = *reinterpret_cast<const float4 *>(shift + cg * 8), t1 = *reinterpret_cast<const float4 *>(shift + cg * 8 + 4);
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        for (int u = 0; u < 3; ++u) {        // (unrolled by the window's period: every slot index is a compile-time constant)
+            const int it = it0 + u;
+            if (it >= FIRST_RUN) break;
+            column(x0 + it + 1, win[(u + 2) % 3]);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float r = a[j] + bb[j];
-        r = r > 0.f ? r : 0.f;
-        a[j] = r * ss[j] + tt[j];
-    }
-    const long plane = (long)H * W * 128;
-    uint16_t *dst = out + pix * 128 + cg * 8;
+            for (int t = 0; t < 9; ++t) {
+                const float v0 = win[(u + t % 3) % 3][t / 3][0], v1 = win[(u + t % 3) % 3][t / 3][1];
+                a0 = __builtin_fmaf(v0, w4[2 * t].x, a0); a1 = __builtin_fmaf(v0, w4[2 * t].y, a1);
+                a2 = __builtin_fmaf(v0, w4[2 * t].z, a2); a3 = __builtin_fmaf(v0, w4[2 * t].w, a3);
+                a0 = __builtin_fmaf(v1, w4[2 * t + 1].x, a0); a1 = __builtin_fmaf(v1, w4[2 * t + 1].y, a1);
+                a2 = __builtin_fmaf(v1, w4[2 * t + 1].z, a2); a3 = __builtin_fmaf(v1, w4[2 * t + 1].w, a3);
+            }
+            float a[4] = {a0 + bb.x, a1 + bb.y, a2 + bb.z, a3 + bb.w};
+            const float sv[4] = {ss.x, ss.y, ss.z, ss.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-        unsigned wd[4];
+            for (int j = 0; j < 4; ++j) {
+                const float r = a[j] > 0.f ? a[j] : 0.f;
+                a[j] = r * sv[j] + tv[j];
+            }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bf16x2 hv;
-            hv[0] = (__bf16)a[2 * q];
-            hv[1] = (__bf16)a[2 * q + 1];
-            wd[q] = __builtin_bit_cast(unsigned, hv);
-            if (pl + 1 < NPL) {
-                a[2 * q] -= __uint_as_float(wd[q] << 16);
-                a[2 * q + 1] -= __uint_as_float(wd[q] & 0xffff0000u);
+            for (int pl = 0; pl < NPL; ++pl) {
+                unsigned wd[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    bf16x2 hv;
+                    hv[0] = (__bf16)a[2 * q];
+                    hv[1] = (__bf16)a[2 * q + 1];
+                    wd[q] = __builtin_bit_cast(unsigned, hv);
+                    if (pl + 1 < NPL) {
+                        a[2 * q] -= __uint_as_float(wd[q] << 16);
+                        a[2 * q + 1] -= __uint_as_float(wd[q] & 0xffff0000u);
+                    }
+                }
+                *reinterpret_cast<uint2 *>(dst + (long)it * 128 + pl * plane) = make_uint2(wd[0], wd[1]);
             }
         }
-        *reinterpret_cast<uint4 *>(dst + pl * plane) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
 }
 

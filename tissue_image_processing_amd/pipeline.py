@@ -74,7 +74,8 @@ class FramePipeline:
             raise RuntimeError("FramePipeline(use_torch=True) is needed for the U-Net path")
         # the projection was written on the library's stream: torch's current stream waits for it (no host round trip)
         _lib.check(self.lib.tip_stream_wait_tip(ctypes.c_void_p(torch.cuda.current_stream(self._proj_t.device).cuda_stream)))
-        img = torch.stack([self._proj_t[atoh_channel].T, self._proj_t[zo_channel].T])
+        # (atoh, zo) planes, each transposed: one straight gather + a strided view (prepare_image transposes back while it reads)
+        img = self._proj_t[[atoh_channel, zo_channel]].transpose(1, 2)
         lab, hc = predictor.predict(img, return_device=True)
         self._unet_labels = lab
         return lab, hc

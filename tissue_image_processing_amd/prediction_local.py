@@ -120,7 +120,7 @@ class _ConvDesc(ctypes.Structure):
                 ("dy", ctypes.c_int * 9), ("dx", ctypes.c_int * 9), ("cout", ctypes.c_int), ("bias", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_h", ctypes.c_int),
                 ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int),
-                ("pool_out", ctypes.c_void_p)]
+                ("pool_out", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("head_out", ctypes.c_void_p)]
 
 
 _FILTERS = (128, 256, 512)
@@ -257,7 +257,11 @@ class _UNet(object):
 
     # -- hand-written convolution path (csrc/tip_unet_conv.h) ---------------------------------------------------------------
     def _split_pack(self, taps, planes):
-        """taps: (T, Cin, Cout) float32 on the device -> packed split weights [T][Cin/16][Cout/128][plane][128][16] bf16."""
+        """taps: (T, Cin, Cout) float32 on the device -> packed split weights [T][Cin/16][Cout/128][plane][128][16] bf16.
+
+        Row order inside every group of 32 output channels: row 8 g + 4 h + j (g < 4, h < 2, j < 4) holds channel 16 h + 4 g + j --
+        the matrix core's output register i = 4 g + j of half-wave h is then channel 16 h + i, i.e. a lane of the kernel ends up with
+        sixteen ADJACENT channels of its pixel (csrc/tip_unet_conv.h, epilogue)."""
         torch = self.torch
         T, cin, cout = taps.shape
         pieces, rest = [], taps.float()
@@ -265,7 +269,10 @@ class _UNet(object):
             h = rest.to(torch.bfloat16)
             pieces.append(h)
             rest = rest - h.float()
-        pk = torch.stack(pieces, 0).view(planes, T, cin // 16, 16, cout // 128, 128)
+        row = torch.arange(32, device=taps.device)
+        chan = 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3)          # channel (within its group of 32) stored in each row
+        pk = torch.stack(pieces, 0).view(planes, T, cin // 16, 16, cout // 32, 32)[..., chan]
+        pk = pk.reshape(planes, T, cin // 16, 16, cout // 128, 128)
         return pk.permute(1, 2, 4, 0, 5, 3).contiguous()
 
     def _hip_weights(self, planes):
@@ -338,7 +345,7 @@ class _UNet(object):
         def buf(h, w, c):
             return torch.empty((planes, h, w, c), dtype=torch.bfloat16, device=x.device)
 
-        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None):
+        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None):
             wp, dy, dx = hw[name]
             cout = wp.shape[2] * 128
             d = _ConvDesc()
@@ -353,15 +360,18 @@ class _UNet(object):
                 d.bias, d.scale, d.shift = hw["f:" + name + ".b"].data_ptr(), hw["f:" + bn + ".s"].data_ptr(), hw["f:" + bn + ".t"].data_ptr()
             else:
                 d.bias, d.scale, d.shift = hw["f:" + bias + ".b"].data_ptr(), None, None
-            if out is None:
+            if head is not None:                  # the network's head in this layer's epilogue: the layer's own output is not stored
+                d.head_w, d.head_b, d.head_out = hw["head"].data_ptr(), hw["f:head.b"].data_ptr(), head.data_ptr()
+                out, oh, ow = None, h, w
+            elif out is None:
                 out, oh, ow = buf(h, w, cout), h, w
-            d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = out.data_ptr(), oh, ow, sy, sx, oy, ox
+            d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = (out.data_ptr() if out is not None else None), oh, ow, sy, sx, oy, ox
             d.pool_out = pooled.data_ptr() if pooled is not None else None
             timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout, len(dy)), 2.0 * h * w * len(dy) * (d.c0 + d.c1) * cout,
                   lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream)))
             return out
 
-        def double(blk, src, skip, h, w, first=False, pooled=None):
+        def double(blk, src, skip, h, w, first=False, pooled=None, head=None):
             if first:
                 a = buf(h, w, 128)
                 timed("first %dx%d 2->128" % (h, w), 2.0 * h * w * 18 * 128,
@@ -369,7 +379,7 @@ class _UNet(object):
                                                                      D(hw["f:d0.b1.t"]), D(a), planes, stream)))
             else:
                 a = conv(blk + ".c1", src, skip, h, w, blk + ".b1")
-            return conv(blk + ".c2", a, None, h, w, blk + ".b2", pooled=pooled)
+            return conv(blk + ".c2", a, None, h, w, blk + ".b2", pooled=pooled, head=head)
 
         def pool(t, h, w):
             o = buf(h // 2, w // 2, t.shape[3])
@@ -396,6 +406,11 @@ class _UNet(object):
                     for px in (0, 1):
                         conv("%s.%d%d" % (name, py, px), cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, oy=py, ox=px, bias=name)
                 h, w = 2 * h, 2 * w
+                fuse_head = i == 2 and not logits and not os.environ.get("TISSUE_HIP_UNET_SEPARATE_HEAD")
+                if fuse_head:                          # softmax probabilities straight out of the last convolution's epilogue
+                    out = torch.empty((1, 2, H, W), dtype=torch.float32, device=x.device)
+                    double("u%d" % i, up, skips[2 - i], h, w, head=out)
+                    return out
                 cur = double("u%d" % i, up, skips[2 - i], h, w)
             out = torch.empty((1, 2, H, W), dtype=torch.float32, device=x.device)
             timed("head %dx%d" % (H, W), 2.0 * H * W * 256,
@@ -503,6 +518,23 @@ class SegmentationPredictor:
         single_in = src_dtype == torch.float32
         t = t.to(torch.float64)                 # exact for every integer / float32 input value
         C, Y, X = t.shape
+        shape1, shape2 = X, Y
+        first_axis_pixels, second_axis_pixels = find_desired_shape(shape1, shape2)
+        npad = ((0, 0), (first_axis_pixels - shape1, 0), (second_axis_pixels - shape2, 0), (0, 0))
+        # One library submission on torch's stream (tip_unet_prepare_f64_dev): the four order statistics of every channel by
+        # radix select, numpy's lerp, clip / scale / transpose / pad in one pass -- nothing comes back to the host.  (The torch
+        # expressions below sort every channel and make a dozen elementwise passes: 2.2 ms of a 2048^2 frame against 0.4.)
+        dense = t.is_cuda and C <= 8 and ((t.stride(1) == 1 and t.stride(2) == Y) or (t.stride(2) == 1 and t.stride(1) == X))
+        if dense and (C == 1 or t.stride(0) >= X * Y) and shares_runtime_with_torch(t) and not os.environ.get("TISSUE_HIP_PREPARE_TORCH"):
+            if self.model_shape != (first_axis_pixels, second_axis_pixels, 2):
+                self.model_shape = (first_axis_pixels, second_axis_pixels, 2)
+            padded = torch.empty((1, C, first_axis_pixels, second_axis_pixels), dtype=torch.float32, device=t.device)
+            kind = 2 if integer_in else (1 if single_in else 0)
+            _lib.check(_lib.lib().tip_unet_prepare_f64_dev(
+                _lib.dptr(t.data_ptr()), C, Y, X, ctypes.c_long(t.stride(0)), ctypes.c_long(t.stride(1)), ctypes.c_long(t.stride(2)), kind,
+                _lib.dptr(padded.data_ptr()), second_axis_pixels, first_axis_pixels,
+                ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
+            return padded, npad
         chans = []
         for c in range(C):
             ch = t[c]
@@ -524,11 +556,8 @@ class SegmentationPredictor:
                 chans.append((clipped - per1) / (per99 - per1))
         norm = torch.stack(chans)                      # (C, Y, X) float64
         xy = norm.permute(0, 2, 1)                     # np.transpose(normalized) -> (X, Y, C); NCHW view: (C, X, Y)
-        shape1, shape2 = X, Y
-        first_axis_pixels, second_axis_pixels = find_desired_shape(shape1, shape2)
         if self.model_shape != (first_axis_pixels, second_axis_pixels, 2):
             self.model_shape = (first_axis_pixels, second_axis_pixels, 2)
-        npad = ((0, 0), (first_axis_pixels - shape1, 0), (second_axis_pixels - shape2, 0), (0, 0))
         padded = torch.zeros((1, C, first_axis_pixels, second_axis_pixels), dtype=torch.float32, device=self.device)
         padded[0, :, npad[1][0]:, npad[2][0]:] = xy.to(torch.float32)
         return padded, npad

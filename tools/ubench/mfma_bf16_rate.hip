@@ -1,0 +1,103 @@
+// mfma_bf16_rate.hip -- what the bf16 matrix pipe sustains on this chip and at which shader clock: back-to-back
+// v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 from registers only (no LDS, no memory), 1 / 2 waves per SIMD, eight
+// independent accumulators per wave.  Wave 0 of block 0 reads s_memtime (shader clock ticks) and s_memrealtime (100 MHz) around
+// its loop: their ratio is the clock the CU really ran at under this load.  Operand values: 0 = all-zero bits, 1 = random bits
+// (data-dependent power).
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_bf16_rate.hip -o /tmp/mfma_bf16_rate && /tmp/mfma_bf16_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int SHAPE>   // 0: 32x32x16 (8 accumulators of 16 registers), 1: 16x16x32 (8 accumulators of 4 registers)
+__global__ void __launch_bounds__(256) k_mfma(float *out, unsigned long long *clk, int iters, const uint4 *seed)
+{
+    const uint4 sa = seed[threadIdx.x & 63], sb = seed[64 + (threadIdx.x & 63)];
+    const bf16x8 a = __builtin_bit_cast(bf16x8, sa), b = __builtin_bit_cast(bf16x8, sb);
+    f32x16 acc[8];
+    f32x4 acd[8];
+    for (int c = 0; c < 8; ++c) {
+        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
+        for (int q = 0; q < 4; ++q) acd[c][q] = 0.f;
+    }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (SHAPE == 0) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+                else acd[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acd[c], 0, 0, 0);
+            }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int c = 0; c < 8; ++c) {
+        for (int q = 0; q < 16; ++q) s += acc[c][q];
+        for (int q = 0; q < 4; ++q) s += acd[c][q];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int SHAPE>
+static void run(int blocks_per_cu, int cus, int iters, int random_bits)
+{
+    float *out;
+    unsigned long long *clk, hclk[2];
+    uint4 *seed, hseed[128];
+    const int blocks = blocks_per_cu * cus;
+    hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+    hipMalloc(&clk, 16);
+    hipMalloc(&seed, sizeof hseed);
+    srand(1);
+    for (int i = 0; i < 128; ++i) {
+        unsigned w[4];
+        for (int j = 0; j < 4; ++j) {
+            // random mantissas and signs with exponents near 1.0 (finite, no denormals): ~ random bf16 pairs
+            const unsigned lo = 0x3f00u | (rand() & 0x80ffu), hi = 0x3f00u | (rand() & 0x80ffu);
+            w[j] = random_bits ? (lo | (hi << 16)) : 0u;
+        }
+        hseed[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    hipMemcpy(seed, hseed, sizeof hseed, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma<SHAPE>, dim3(blocks), dim3(256), 0, 0, out, clk, 100, seed);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_mfma<SHAPE>, dim3(blocks), dim3(256), 0, 0, out, clk, iters, seed);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+    const double per = SHAPE == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32;
+    const double flop = (double)blocks * 4 * (double)iters * 24 * per;
+    const double mhz = (double)hclk[0] / ((double)hclk[1] / 100.0);    // shader ticks per microsecond of the 100 MHz counter
+    const double cyc_per_mfma = (double)hclk[0] / ((double)iters * 24 * blocks_per_cu);   // per SIMD: blocks_per_cu waves share it
+    printf("%s, %d wave(s)/SIMD, %s operands: %.3f ms, %.0f TFLOP/s (%.1f %% of 2500), shader clock %.0f MHz, %.1f clocks per MFMA per SIMD\n",
+           SHAPE == 0 ? "32x32x16" : "16x16x32", blocks_per_cu, random_bits ? "random" : "zero", ms, flop / ms / 1e9,
+           100.0 * flop / ms / 1e9 / 2500.0, mhz, cyc_per_mfma);
+    hipFree(out); hipFree(clk); hipFree(seed);
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    printf("%s, %d CUs, clockRate %d kHz\n", p.name, cus, p.clockRate);
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        run<0>(1, cus, 20000, rnd);
+        run<0>(2, cus, 10000, rnd);
+        run<1>(1, cus, 40000, rnd);
+        run<1>(2, cus, 20000, rnd);
+    }
+    // a long run: does the clock sag as the chip warms up?
+    run<0>(2, cus, 100000, 1);
+    return 0;
+}
