@@ -393,6 +393,12 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     }
     p.zeros = (const uint16_t *)c.zero_page;
     p.pool_out = (uint16_t *)d->pool_out;
+#ifdef UC_TRACE
+    static unsigned long long *trace_dev = nullptr;
+    if (!trace_dev) { TIP_HIP(hipMalloc(&trace_dev, 512)); }
+    TIP_HIP(hipMemsetAsync(trace_dev, 0, 512, (hipStream_t)stream));
+    p.trace = trace_dev;
+#endif
     p.head_w = d->head_w; p.head_b = d->head_b; p.head_out = d->head_out;
     if (d->head_out && (!d->head_w || !d->head_b || d->cout != UC_BN || !d->scale || d->pool_out || d->sy != 1 || d->sx != 1 || d->oy != 0 || d->ox != 0 ||
                         d->out_h != d->h || d->out_w != d->w))
@@ -425,6 +431,20 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     else if (which == 4) hipLaunchKernelGGL((k_unet_conv<2, 16, 2, 2>), grid, dim3(threads), lds, s, p);
     else if (which == 1) hipLaunchKernelGGL((k_unet_conv<2, 16, 2>), grid, dim3(threads), lds, s, p);
     else hipLaunchKernelGGL((k_unet_conv<2, 8, 2>), grid, dim3(threads), lds, s, p);
+#ifdef UC_TRACE
+    {
+        unsigned long long tr[64];
+        TIP_HIP(hipStreamSynchronize(s));
+        TIP_HIP(hipMemcpy(tr, trace_dev, sizeof tr, hipMemcpyDeviceToHost));
+        for (int k = 0; k < th / 2; ++k) {
+            const unsigned long long *t = tr + 8 * k;
+            const double n = (double)t[4];
+            fprintf(stderr, "UC_TRACE th %d taps %d cin %d cout %d grid %dx%d wave %d simd %d: per step (shader clocks): copies %.0f, products %.0f (first MFMA out after %.0f), "
+                            "vmcnt wait %.0f, barrier %.0f, total %.0f; steps %.0f\n",
+                    th, d->ntaps, d->c0 + d->c1, d->cout, d->h, d->w, k, (int)((t[7] >> 4) & 3), t[0] / n, t[2] / n, t[1] / n, t[6] / n, (t[3] - t[6]) / n, t[5] / n, n);
+        }
+    }
+#endif
     return unet_launch_check("unet_conv");
 }
 

@@ -55,6 +55,9 @@ struct ConvParams {
     const uint16_t *zeros;         // >= 16 bytes of zeros on the device: the source of halo pixels outside the image
     const float *head_w, *head_b;  // nullptr, or the network's head fused into this layer's epilogue (cout == 128, plain output mapping):
     float *head_out;               //   Conv2D(128 -> 2, 1x1) weights [2][128], bias [2] -> softmax -> float32 (2, H, W); `out` is then not written
+#ifdef UC_TRACE
+    unsigned long long *trace;     // diagnostic build: clock sums of block 0 / wave 0 (tools/unet_trace.py)
+#endif
     uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
@@ -86,6 +89,17 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 // A counted wait on the vector-memory queue followed by the workgroup barrier.  The asynchronous global -> LDS copies of
 // LATER steps stay in flight across the barrier (a __syncthreads() would drain them: its fence waits for vmcnt(0) while an
 // LDS-DMA is pending), so the count is the number of copy instructions this wave issued AFTER the ones it must see landed.
+#ifdef UC_TRACE
+__device__ unsigned long long uc_trace_wait_ticks;      // (diagnostic build only) never read: the per-wave sum lives in a register
+template <int N>
+__device__ __forceinline__ unsigned long long uc_wait_barrier_timed()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return t;
+}
+#endif
 template <int N>
 __device__ __forceinline__ void uc_wait_barrier()
 {
@@ -117,6 +131,7 @@ __device__ __forceinline__ void uc_wait_barrier()
 template <int NPL, int TH, int D, int DA = 1>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
+#if defined(__HIP_DEVICE_COMPILE__)       // (the buffer-resource builtins exist in the device pass only; the host pass needs just the stub)
     static_assert(DA == 1 || (DA == 2 && D == 2), "two-chunk activation prefetch: with the two-step weight schedule");
     constexpr int UC_NBBUF = D + 1;
     constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
@@ -139,15 +154,15 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
 
     // ---- copy plans (fixed per thread) ------------------------------------------------------------------------------------
-    // activation slot q = u * 256 + tid: plane, halo pixel, stored half -> image pixel and logical half.  Recomputed at every
-    // chunk (a few dozen scalar-ish operations against nine steps of MFMAs): the main loop needs the registers.
-    auto copy_a = [&](int chunk, int buf) {
-        const int cbase = chunk * UC_KC;
-        const bool second = cbase >= p.c0;
-        const uint16_t *src = second ? p.in1 : p.in0;
-        const int C = second ? p.c1 : p.c0, cc = second ? cbase - p.c0 : cbase;
-        const long plane_stride = second ? in_plane1 : in_plane0;
-        lds_byte *dst = (lds_byte *)(sA + buf * A_BYTES + wave * 64 * 16);
+    // The tiles arrive by buffer_load_dwordx4 ... lds: a buffer resource (scalar registers: base, extent) + a per-lane byte offset
+    // that is FIXED for the whole kernel + a scalar offset that moves with the chunk / step.  A step's copies are then a handful of
+    // scalar instructions and the copy itself -- no vector arithmetic: clock counters inside the kernel (tools/unet_trace.sh)
+    // showed every step opening with ~210 clocks of copy addressing in all waves, during which the matrix pipe had nothing to
+    // issue, and vector instructions of one wave also delay its SIMD partner's MFMAs.  Halo pixels outside the image (and the
+    // padding slots) carry an offset beyond the resource's extent: the hardware's range check returns zeros for them.
+    // activation slot q = u * THREADS + tid: plane, halo pixel, stored half -> image pixel and logical half
+    unsigned a_off[A_PER];
+    auto plan_a = [&](int C, long plane_stride) {
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             const int q = u * UC_THREADS + tid;
@@ -155,19 +170,41 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             const int hy = px / UC_HW, hx = px - hy * UC_HW;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const uint16_t *g = inside ? src + pl * plane_stride + ((long)gy * p.W + gx) * C + cc + half * 8 : p.zeros;
-            __builtin_amdgcn_global_load_lds(g, dst + u * UC_THREADS * 16, 16, 0, 0);
+            a_off[u] = inside ? (unsigned)((pl * plane_stride + ((long)gy * p.W + gx) * C + half * 8) * 2) : 0xfffffff0u;
+        }
+    };
+    plan_a(p.c0, in_plane0);
+    bool a_second = false;                  // the offsets are those of in1 (they depend on the channel count)
+    constexpr int RSRC_FLAGS = 0x00020000;  // raw buffer, 32-bit data format (gfx9 resource word 3)
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.in0, 0, (int)(unsigned)(NPL * in_plane0 * 2), RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.in1, 0, (int)(unsigned)(NPL * in_plane1 * 2), RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)0xffffffffu, RSRC_FLAGS);
+    auto copy_a = [&](int chunk, int buf) {
+        const int cbase = chunk * UC_KC;
+        const bool second = cbase >= p.c0;
+        if (second && !a_second) {          // (once per kernel, and only when a second input exists)
+            a_second = true;
+            if (p.c1 != p.c0) plan_a(p.c1, in_plane1);
+        }
+        const int soff = (second ? cbase - p.c0 : cbase) * 2;
+        lds_byte *dst = (lds_byte *)(sA + buf * A_BYTES + wave * 64 * 16);
+        if (second) {
+#pragma unroll
+            for (int u = 0; u < A_PER; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, dst + u * UC_THREADS * 16, 16, a_off[u], soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < A_PER; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, dst + u * UC_THREADS * 16, 16, a_off[u], soff, 0, 0);
         }
     };
     // weight slot q = u * THREADS + tid = (plane q / 256, n = (q % 256) / 2, stored half q & 1)
     const int bq = tid & 255;
-    const int b_src = (tid >> 8) * (UC_BN * UC_KC) + (bq >> 1) * UC_KC + (((bq & 1) ^ ((bq >> 4) & 1))) * 8;   // element offset inside the step's tile
+    const unsigned b_off = (unsigned)(((tid >> 8) * (UC_BN * UC_KC) + (bq >> 1) * UC_KC + (((bq & 1) ^ ((bq >> 4) & 1))) * 8) * 2);   // byte offset inside the step's tile
     auto copy_b = [&](int chunk, int tap, int buf) {
-        const uint16_t *src = p.w + (((long)tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC) + b_src;
+        const int soff = ((tap * nchunks + chunk) * nblks + nblk) * (NPL * UC_BN * UC_KC * 2);        // (a layer's packed weights stay below 2 GB)
         lds_byte *dst = (lds_byte *)(sB + buf * B_BYTES + wave * 64 * 16);
 #pragma unroll
         for (int u = 0; u < B_PER; ++u)
-            __builtin_amdgcn_global_load_lds(src + u * (UC_THREADS / 256) * (UC_BN * UC_KC), dst + u * UC_THREADS * 16, 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst + u * UC_THREADS * 16, 16, b_off, soff + u * (UC_THREADS / 256) * (UC_BN * UC_KC * 2), 0, 0);
     };
 
     // Accumulators: D = W^T X^T -- the WEIGHT fragment is the matrix core's A operand, so a lane holds ONE pixel (column lane & 31)
@@ -194,8 +231,28 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     int nc = D / p.ntaps, nt = D % p.ntaps;                  // (chunk, tap) of step + D
     int buf0 = 0, buf2 = D;                                  // weight buffers of steps s and s + D (no division in the loop)
     bf16x8 fa[2][NPL], fb[4][NPL];
-    // fragments of step (chunk, tap), the operands of the first product group first
-    auto load_frags = [&](int chunk, int tap) {
+#ifdef UC_TRACE
+    // clock sums over the main loop for ONE wave (block 0, wave 0): [0] copies issued, [1] fragment reads issued .. first operands
+    // there (inside step_products), [2] products issued, [3] wait + barrier, [4] steps, [5] loop total
+    unsigned long long tr_copy = 0, tr_read = 0, tr_mfma = 0, tr_bar = 0, tr_t0 = __builtin_amdgcn_s_memtime();
+    const bool tracing = blockIdx.x == 0 && blockIdx.y == 0;
+    unsigned long long tr_wait = 0, t_w = 0;
+#define UC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define UC_WB t_w = uc_wait_barrier_timed
+#else
+#define UC_T(var)
+#define UC_WB uc_wait_barrier
+#endif
+    // One step's fragments and products.  A step opens behind a barrier, so all eight waves read at once: 96 KB through the CU's
+    // 128-byte-per-clock LDS port, ~770 clocks.  The products therefore start as soon as the operands of the FIRST product group
+    // (the low activation piece x the high weight piece: 6 of the 12 fragments) are there, and the other six reads are issued
+    // behind that group's first MFMA, where they run in the matrix pipe's shadow (sched_barrier pins the order; left to itself the
+    // compiler issues all twelve reads and waits for all of them in front of the first MFMA).
+    // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
+#define UC_PRODUCT(PA, PB)                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][PB], fa[m][PA], acc[m][n], 0, 0, 0);
+    auto step_products = [&](int chunk, int tap) {
         const unsigned char *abuf = sA + (chunk % (DA + 1)) * A_BYTES;
         const unsigned char *bbuf = sB + buf0 * B_BYTES;
         const int dy = p.dy[tap], dx = p.dx[tap];
@@ -205,38 +262,56 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
             aslot[m] = px * 2 + (h ^ ((px >> 3) & 1));
         }
+        auto read_a = [&](int m, int pl) { fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + (pl * UC_HP * 2 + aslot[m]) * 16)); };
+        auto read_b = [&](int n, int pl) { fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16)); };
+        if constexpr (NPL == 2) {
+            read_a(0, 1); read_a(1, 1);
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
+            for (int n = 0; n < 4; ++n) read_b(n, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][0], fa[0][1], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0, 0); read_a(1, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                fa[m][NPL - 1 - k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + ((NPL - 1 - k) * UC_HP * 2 + aslot[m]) * 16));
+            for (int n = 0; n < 4; ++n) read_b(n, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                fb[n][k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (k * 256 + n * 64 + b_row) * 16));
+            for (int n = 1; n < 4; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][0], fa[0][1], acc[0][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][0], fa[1][1], acc[1][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            UC_PRODUCT(0, 1)
+            UC_PRODUCT(0, 0)
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) read_a(m, NPL - 1 - k);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) read_b(n, k);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2)
+            UC_PRODUCT(1, 0)
+            UC_PRODUCT(0, 1)
+            UC_PRODUCT(0, 0)
+            __builtin_amdgcn_s_setprio(0);
         }
-    };
-    // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
-#define UC_PRODUCT(PA, PB)                                                                                      \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][PB], fa[m][PA], acc[m][n], 0, 0, 0);
-    auto products = [&]() {
-        __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
-        if constexpr (NPL == 3) { UC_PRODUCT(2, 0) UC_PRODUCT(1, 1) UC_PRODUCT(0, 2) }
-        UC_PRODUCT(1, 0)
-        UC_PRODUCT(0, 1)
-        UC_PRODUCT(0, 0)
-        __builtin_amdgcn_s_setprio(0);
     };
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < p.ntaps; ++tap, ++step) {
+            UC_T(t_a);
             // copies: the next chunk's activations at the chunk's first tap, the weights of step + D
             const bool issue_a = tap == 0 && chunk + DA < nchunks;
             const bool issue_b = step + D < nsteps;
             if (issue_a) copy_a(chunk + DA, (chunk + DA) % (DA + 1));
             if (issue_b) copy_b(nc, nt, buf2);
+            UC_T(t_b);
+            step_products(chunk, tap);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
-            load_frags(chunk, tap);
-            products();
+            UC_T(t_c);
             // Before the barrier the weights of step + 1 must have landed (issued one step ago, before everything issued in
             // this step) and, when the next step opens a new chunk, its activations too.  Issue order inside a step is
             // activations first, weights second, so "at most B_PER outstanding" also covers the activations.
@@ -244,9 +319,9 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
                 // (DA == 2: the tile the next step may need was issued at least a step ago, before the weights waited for here)
                 const bool need_a_now = DA == 1 && issue_a && p.ntaps == 1;
                 if (issue_b) {
-                    if (issue_a && !need_a_now) uc_wait_barrier<A_PER + B_PER>(); else uc_wait_barrier<B_PER>();
+                    if (issue_a && !need_a_now) UC_WB<A_PER + B_PER>(); else UC_WB<B_PER>();
                 } else {
-                    if (issue_a && !need_a_now) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>();
+                    if (issue_a && !need_a_now) UC_WB<A_PER>(); else UC_WB<0>();
                 }
             } else {
                 // newer than the weights of step + 1: the weight copies of steps step + 2 .. step + D that exist, and the next
@@ -254,18 +329,29 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
                 const int left = nsteps - (step + 2);
                 const int nb = left < 0 ? 0 : (left > D - 1 ? D - 1 : left);
                 const bool a_out = tap <= D - 2 && chunk + 1 < nchunks;
-#define UC_WAIT_CASE(NB_) case NB_: if (a_out) uc_wait_barrier<NB_ * B_PER + A_PER>(); else uc_wait_barrier<NB_ * B_PER>(); break;
+#define UC_WAIT_CASE(NB_) case NB_: if (a_out) UC_WB<NB_ * B_PER + A_PER>(); else UC_WB<NB_ * B_PER>(); break;
                 switch (nb) {
                     UC_WAIT_CASE(0) UC_WAIT_CASE(1) UC_WAIT_CASE(2)
-                    default: if (a_out) uc_wait_barrier<(D - 1) * B_PER + A_PER>(); else uc_wait_barrier<(D - 1) * B_PER>(); break;
+                    default: if (a_out) UC_WB<(D - 1) * B_PER + A_PER>(); else UC_WB<(D - 1) * B_PER>(); break;
                 }
 #undef UC_WAIT_CASE
                 static_assert(D <= 4, "wait cases cover D <= 4");
             }
             buf0 = buf0 + 1 == UC_NBBUF ? 0 : buf0 + 1;
             buf2 = buf2 + 1 == UC_NBBUF ? 0 : buf2 + 1;
+#ifdef UC_TRACE
+            UC_T(t_d);
+            tr_copy += t_b - t_a; tr_mfma += t_c - t_b; tr_bar += t_d - t_c; tr_wait += t_w - t_c;
+#endif
         }
     }
+#ifdef UC_TRACE
+    if (tracing && p.trace && lane == 0) {
+        unsigned long long *tp = p.trace + 8 * wave;
+        tp[0] = tr_copy; tp[1] = tr_read; tp[2] = tr_mfma; tp[3] = tr_bar; tp[4] = (unsigned long long)nsteps;
+        tp[5] = __builtin_amdgcn_s_memtime() - tr_t0; tp[6] = tr_wait; tp[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 #undef UC_PRODUCT
 
     // ---- epilogue: bias [-> ReLU -> scale, shift], split, store through LDS -----------------------------------------------------------
@@ -429,6 +515,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             }
         }
     }
+#endif
 }
 
 // ---- first layer: Conv2D(2 -> 128, 3x3) on the float32 (2, H, W) network input --------------------------------------------------
@@ -484,16 +571,16 @@ __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict
             const int it = it0 + u;
             if (it >= FIRST_RUN) break;
             column(x0 + it + 1, win[(u + 2) % 3]);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};       // packed FMAs: two channels per instruction
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float v0 = win[(u + t % 3) % 3][t / 3][0], v1 = win[(u + t % 3) % 3][t / 3][1];
-                a0 = __builtin_fmaf(v0, w4[2 * t].x, a0); a1 = __builtin_fmaf(v0, w4[2 * t].y, a1);
-                a2 = __builtin_fmaf(v0, w4[2 * t].z, a2); a3 = __builtin_fmaf(v0, w4[2 * t].w, a3);
-                a0 = __builtin_fmaf(v1, w4[2 * t + 1].x, a0); a1 = __builtin_fmaf(v1, w4[2 * t + 1].y, a1);
-                a2 = __builtin_fmaf(v1, w4[2 * t + 1].z, a2); a3 = __builtin_fmaf(v1, w4[2 * t + 1].w, a3);
+                a01 = __builtin_elementwise_fma(f32x2{v0, v0}, f32x2{w4[2 * t].x, w4[2 * t].y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2{v0, v0}, f32x2{w4[2 * t].z, w4[2 * t].w}, a23);
+                a01 = __builtin_elementwise_fma(f32x2{v1, v1}, f32x2{w4[2 * t + 1].x, w4[2 * t + 1].y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2{v1, v1}, f32x2{w4[2 * t + 1].z, w4[2 * t + 1].w}, a23);
             }
-            float a[4] = {a0 + bb.x, a1 + bb.y, a2 + bb.z, a3 + bb.w};
+            float a[4] = {a01[0] + bb.x, a01[1] + bb.y, a23[0] + bb.z, a23[1] + bb.w};
             const float sv[4] = {ss.x, ss.y, ss.z, ss.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
