@@ -673,7 +673,9 @@ def main():
         if tr_paths and (hp, wp) == (2048, 2048) and info.get("issued_flops_factor", 1) == 3:
             recs = json.load(open(tr_paths[-1]))
             tot = sum((v["fetch_MB_per_call_x2corrected"] + v["write_MB_per_call"]) * v["calls"] for k, v in recs.items() if k.startswith("k_unet_"))
-            passes = max(1, min(v["calls"] for k, v in recs.items() if k.startswith("k_unet_head")))
+            # forward passes in that counter run: the first layer is launched once per pass (the head is fused into the last convolution)
+            per_pass = [v["calls"] for k, v in recs.items() if k.startswith("k_unet_conv_first")] or [v["calls"] for k, v in recs.items() if k.startswith("k_unet_head")]
+            passes = max(1, min(per_pass)) if per_pass else 1
             r["traffic"] = tot * 1e6 / passes
             r["algorithmic_bytes"] = plm.unet_algorithmic_bytes(hp, wp)
             r["traffic_ratio"] = r["traffic"] / r["algorithmic_bytes"]

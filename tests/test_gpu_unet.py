@@ -84,6 +84,28 @@ def test_prepare_image_fused_pass_equals_torch_expressions(case, monkeypatch):
         assert torch.equal(fused, ref)
 
 
+@pytest.mark.parametrize("shape", [(300, 421), (64, 64), (65, 129), (7, 500), (1, 40), (3, 3), (1024, 1024)])
+def test_tail_morphology_in_one_kernel_equals_the_rank_filter_chain(shape):
+    """pl.py:168-193 (threshold, 5x5 closing, 7x7 erosion, boundary dilation) as one byte-image kernel against the same chain as
+    separate float64 rank-filter launches (themselves pinned by the golden `unet_tail`): HC maps and labels bit for bit, on extents
+    that are smaller than the 9-pixel halo, not multiples of the 64-pixel tile, and on blobs that touch the borders."""
+    import torch
+    from tissue_image_processing_amd import prediction_local as pl, _lib
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    p0 = 0.5 + 0.5 * np.sin(yy / 3.7) * np.cos(xx / 5.3) + 0.15 * rng.standard_normal(shape)
+    pred = pl.SegmentationPredictor(None, (2,) + shape)
+    t = torch.as_tensor(p0.astype(np.float32), device=pred.device)
+    lab, hc = pred.segment_probability(t, thr=0.5)
+    with _lib.tuning(TIP_UNET_TAIL_UNFUSED="1"):
+        lab_u, hc_u = pred.segment_probability(t, thr=0.5)
+    np.testing.assert_array_equal(hc, hc_u)
+    np.testing.assert_array_equal(lab, lab_u)
+    lab64, hc64 = pred.segment_probability(t.double(), thr=0.5)       # float64 probability maps take the same kernel
+    np.testing.assert_array_equal(hc64, hc)
+    np.testing.assert_array_equal(lab64, lab)
+
+
 class _FakeNet(object):
     """Stands in for the trained network (no weights ship with the reference): returns a fixed class-probability map."""
 

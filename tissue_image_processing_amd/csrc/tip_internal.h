@@ -65,6 +65,8 @@ struct Tuning {
     int project_generic = 0, project_unfused_preblur = 0, project_unfused_mask = 0;
     int project_exact_score = 0, project_debug = 0;
     int fast_cfg_y = -1, fast_cfg_x = -1;    // TIP_FAST_CFG=y,x
+    int unet_tail_unfused = 0;  // TIP_UNET_TAIL_UNFUSED: the tail's morphology as separate rank-filter launches (tests)
+    int unet_xcd_map = 1;       // TIP_UNET_XCD_MAP: the channel blocks of one pixel tile side by side on one XCD (0: all workgroups in flight on one channel block)
     int unet_tile8 = -1;        // TIP_UNET_TILE8: the U-Net convolution's tile rows: 1 = 8 everywhere, 0 = 16 where the grid allows, -1 (default) = 16 except for 3x3 layers with <= 128 input channels
 };
 const Tuning &tuning();

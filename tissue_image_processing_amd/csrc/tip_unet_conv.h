@@ -58,6 +58,7 @@ struct ConvParams {
 #ifdef UC_TRACE
     unsigned long long *trace;     // diagnostic build: clock sums of block 0 / wave 0 (tools/unet_trace.py)
 #endif
+    int xcd_map;                   // workgroup -> (tile, channel block) mapping, see the kernel
     uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
@@ -148,8 +149,23 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the copies go to M0 without a waterfall loop)
     const int tilesX = p.W / UC_TW;
-    const int tile = blockIdx.x, ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * UC_TW;
-    const int nblk = blockIdx.y, nblks = p.cout / UC_BN;
+    const int nblks = p.cout / UC_BN;
+    // Workgroup -> (pixel tile, block of 128 output channels).  Plain order: grid (tiles, blocks) -- every workgroup in flight works
+    // on the SAME channel block (its weights stay in L2) but the input is streamed from HBM once per block (up to eight times).
+    // XCD order (p.xcd_map; 1-D grid of tiles x blocks, tiles % 8 == 0): the hardware deals workgroup b to XCD b % 8, so with
+    // j = b / 8 the workgroups j = 0 .. nblks - 1 of one XCD are the channel blocks of ONE pixel tile: they run side by side and
+    // the tile's activations come out of that XCD's L2 for all but the first of them; the weights of all blocks then stream through
+    // each L2 from the memory-side cache (a layer's packed weights are at most 38 MB).
+    int tile, nblk;
+    if (p.xcd_map) {
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        tile = (j / nblks) * 8 + xcd;
+        nblk = j - (j / nblks) * nblks;
+    } else {
+        tile = blockIdx.x;
+        nblk = blockIdx.y;
+    }
+    const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * UC_TW;
     const int cin = p.c0 + p.c1, nchunks = cin / UC_KC, nsteps = nchunks * p.ntaps;
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
 
