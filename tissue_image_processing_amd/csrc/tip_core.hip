@@ -255,7 +255,6 @@ int tip_shutdown(void)
     for (auto &r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto &e : c->free_events) (void)hipEventDestroy(e);
     if (c->edge_event) (void)hipEventDestroy(c->edge_event);
-    if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->prep_ws) (void)hipFree(c->prep_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -25,7 +25,6 @@ struct Ctx {
     int last_ws_labels = 0;   // marker count of this thread's last watershed (tip_last_watershed_labels)
     long last_ws_other = 0;   // ... and its number of pixels that are neither the image's minimum nor its maximum
     hipEvent_t edge_event = nullptr;   // tip_wait_stream / tip_stream_wait_tip
-    void *zero_page = nullptr;         // 256 zero bytes on the device (tip_unet_conv_dev)
     void *prep_ws = nullptr;           // order-statistic state of tip_unet_prepare_f64_dev (used on the caller's stream only)
     bool prof = false;
     std::vector<ProfRec> recs;

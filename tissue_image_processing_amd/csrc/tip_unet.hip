@@ -464,11 +464,6 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     }
     p.cout = d->cout; p.bias = d->bias; p.scale = d->scale; p.shift = d->shift;
     p.out = (uint16_t *)d->out; p.outH = d->out_h; p.outW = d->out_w; p.sy = d->sy; p.sx = d->sx; p.oy = d->oy; p.ox = d->ox;
-    if (!c.zero_page) {     // source of halo pixels outside the image (the copies go global -> LDS, a register zero cannot be written)
-        TIP_HIP(hipMalloc(&c.zero_page, 256));
-        TIP_HIP(hipMemset(c.zero_page, 0, 256));
-    }
-    p.zeros = (const uint16_t *)c.zero_page;
     p.pool_out = (uint16_t *)d->pool_out;
 #ifdef UC_TRACE
     static unsigned long long *trace_dev = nullptr;

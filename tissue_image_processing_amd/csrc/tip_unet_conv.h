@@ -52,7 +52,6 @@ struct ConvParams {
     const float *bias, *scale, *shift;   // scale == nullptr: bias only (Conv2DTranspose); else bias -> ReLU -> scale, shift
     uint16_t *out;                 // [plane][outH][outW][cout]
     int outH, outW, sy, sx, oy, ox;       // output pixel of input-grid pixel (y, x): (y * sy + oy, x * sx + ox)
-    const uint16_t *zeros;         // >= 16 bytes of zeros on the device: the source of halo pixels outside the image
     const float *head_w, *head_b;  // nullptr, or the network's head fused into this layer's epilogue (cout == 128, plain output mapping):
     float *head_out;               //   Conv2D(128 -> 2, 1x1) weights [2][128], bias [2] -> softmax -> float32 (2, H, W); `out` is then not written
 #ifdef UC_TRACE
