@@ -14,18 +14,22 @@
 // BatchNorm scale / shift, all in float32 on the accumulator) does the split.  Weights are split once when the model is loaded.
 //
 // Decomposition.  out[pixel, n] = sum over taps t and input channels c of in[pixel + (dy_t, dx_t), c] * w[t][c][n]: a GEMM with
-// M = pixels, N = output channels, K = taps * Cin.  A workgroup (256 threads, 4 waves) owns an 8 x 32-pixel tile x 128 output
-// channels; the K loop walks the input channels in chunks of 16 and, inside a chunk, the taps:
-//   * the chunk's (8 + 2) x (32 + 2)-pixel halo tile of the activation is staged ONCE in LDS (zero outside the image) and every
+// M = pixels, N = output channels, K = taps * Cin.  A workgroup owns a TH x 32-pixel tile (TH = 16: eight waves, one workgroup per
+// CU; TH = 8: four waves, two per CU) x 128 output channels; the K loop walks the input channels in chunks of 16 and, inside a
+// chunk, the taps:
+//   * the chunk's (TH + 2) x (32 + 2)-pixel halo tile of the activation is staged ONCE in LDS (zero outside the image) and every
 //     tap reads its shifted window from there -- the nine taps of a 3x3 stencil re-use one staged tile;
-//   * the weights of one (chunk, tap) -- 16 x 128 values per plane -- are double-buffered in LDS, the next step's tile is
-//     fetched into registers while the matrix cores work on the current one;
+//   * the weights of one (chunk, tap) step -- 16 x 128 values per plane -- sit in one of D + 1 LDS buffers; activations and weights
+//     arrive by asynchronous buffer_load ... lds copies issued D steps / a chunk ahead (no staging registers, no vector arithmetic:
+//     per-lane offsets are fixed for the kernel, the step's offset is scalar);
 //   * a wave computes 64 pixels (two tile rows) x 128 channels: 2 x 4 accumulator tiles of v_mfma_f32_32x32x16_bf16, the 16
-//     channels of a chunk being exactly the K of one MFMA.  LDS rows are padded to 48 bytes so that the 16-lane groups of
-//     ds_read_b128 hit 16 different bank quads (MI355X_MICROARCH.md, LDS table).
+//     channels of a chunk being exactly the K of one MFMA, formed TRANSPOSED (weights = the A operand) so that a lane ends up with
+//     one pixel and sixteen adjacent channels per 32-channel block -- the epilogue splits and stores without a lane exchange.
+//     LDS rows are 32 bytes, unpadded, conflict-free for ds_read_b128 through an XOR swizzle applied on the copy's source side.
 // Two inputs (in0 with c0 channels, then in1 with c1) are read as one concatenated tensor: the decoder's
 // concatenate([upsampled, skip]) (pl.py:52) never exists in memory.  A stride-2 transposed convolution is four such
-// convolutions, one per output parity class, with 1 / 2 / 2 / 4 taps and a strided output (tap lists built by the caller).
+// convolutions, one per output parity class, with 4 / 2 / 2 / 1 taps and a strided output (tap lists built by the caller).
+// The kernel body has the details next to the code; DESIGN.md 5.7 has the measurements (clock trace, power-limited MFMA ceiling).
 #pragma once
 #include "tip_internal.h"
 
@@ -112,8 +116,8 @@ __device__ __forceinline__ void uc_wait_barrier()
 // and D + 1 weight buffers of NPL * 256 slots -- slot (plane * 128 + n) * 2 + sh.  A row (one pixel / one output channel) is
 // 16 bf16 = 32 bytes = two slots; the two halves of row j are stored SWAPPED when bit 3 of j is set (sh = half ^ ((j >> 3) & 1)):
 // the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} of consecutive rows, one half each) then hit 16
-// different bank quads with unpadded rows, which is what lets the tiles arrive by global_load_lds (a wave's 64 x 16 bytes land
-// in 64 consecutive slots; the swizzle is applied to the per-lane SOURCE address).
+// different bank quads with unpadded rows, which is what lets the tiles arrive by asynchronous ... lds copies (a wave's 64 x 16
+// bytes land in 64 consecutive slots; the swizzle is applied to the per-lane SOURCE offset).
 //
 // TH = tile rows = 2 per wave: 8 (256 threads, two workgroups per CU) or 16 (512 threads, one per CU).  The weight tile of a step
 // is shared by all the workgroup's waves, so the taller tile halves the weight bytes copied per MFMA -- and the copies are what
