@@ -66,7 +66,7 @@ struct Tuning {
     int fast_cfg_y = -1, fast_cfg_x = -1;    // TIP_FAST_CFG=y,x
     int unet_tail_unfused = 0;  // TIP_UNET_TAIL_UNFUSED: the tail's morphology as separate rank-filter launches (tests)
     int unet_xcd_map = 1;       // TIP_UNET_XCD_MAP: the channel blocks of one pixel tile side by side on one XCD (0: all workgroups in flight on one channel block)
-    int unet_no_pair = 0;       // TIP_UNET_NO_PAIR: one step per barrier in every convolution kernel (default: two in the 3x3 16-row kernel)
+    int unet_spb = 3;           // TIP_UNET_SPB: steps per barrier of the 3x3 16-row convolution kernel (1, 2 or 3)
     int unet_tile8 = -1;        // TIP_UNET_TILE8: the U-Net convolution's tile rows: 1 = 8 everywhere, 0 = 16 where the grid allows, -1 (default) = 16 except for 3x3 layers with <= 128 input channels
 };
 const Tuning &tuning();

@@ -491,20 +491,25 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     p.xcd_map = (tuning().unet_xcd_map && nblks > 1 && ntiles % 8 == 0) ? 1 : 0;
     const dim3 grid = p.xcd_map ? dim3((unsigned)(ntiles * nblks)) : dim3(ntiles, nblks);
     const int a_per = (d->planes * hp * 2 + threads - 1) / threads;
-    // two steps per barrier: 3x3 stencils on 16-row tiles with an even number of steps (six weight buffers)
-    const bool pair = th == 16 && dist == 4 && d->ntaps == 9 && (((d->c0 + d->c1) / UC_KC) & 1) == 0 && !tuning().unet_no_pair;
-    const size_t lds = (size_t)(da + 1) * a_per * threads * 16 + (size_t)(pair ? 6 : dist + 1) * d->planes * 256 * 16;
+    // several steps per barrier: 3x3 stencils on 16-row tiles; three (a chunk's nine taps in three iterations, nine weight buffers)
+    // or two (six buffers; needs an even number of steps)
+    const int spb_want = tuning().unet_spb;
+    const bool multi = th == 16 && dist == 4 && d->ntaps == 9 && spb_want > 1;
+    const int spb = !multi ? 1 : (spb_want >= 3 ? 3 : ((((d->c0 + d->c1) / UC_KC) & 1) == 0 ? 2 : 1));
+    const size_t lds = (size_t)(da + 1) * a_per * threads * 16 + (size_t)(spb > 1 ? 3 * spb : dist + 1) * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set[6] = {false, false, false, false, false, false};
-    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? (pair ? 5 : 2) : (da == 2 ? 4 : 1)) : 0);
+    static bool attr_set[7] = {false, false, false, false, false, false, false};
+    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? (spb == 3 ? 6 : (spb == 2 ? 5 : 2)) : (da == 2 ? 4 : 1)) : 0);
     const void *fn = which == 3 ? (const void *)k_unet_conv<3, 8, 2>
-                   : which == 5 ? (const void *)k_unet_conv<2, 16, 4, 1, true>
+                   : which == 6 ? (const void *)k_unet_conv<2, 16, 4, 1, 3>
+                   : which == 5 ? (const void *)k_unet_conv<2, 16, 4, 1, 2>
                    : which == 2 ? (const void *)k_unet_conv<2, 16, 4>
                    : which == 4 ? (const void *)k_unet_conv<2, 16, 2, 2>
                    : which == 1 ? (const void *)k_unet_conv<2, 16, 2> : (const void *)k_unet_conv<2, 8, 2>;
     if (!attr_set[which]) { TIP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[which] = true; }
     if (which == 3) hipLaunchKernelGGL((k_unet_conv<3, 8, 2>), grid, dim3(threads), lds, s, p);
-    else if (which == 5) hipLaunchKernelGGL((k_unet_conv<2, 16, 4, 1, true>), grid, dim3(threads), lds, s, p);
+    else if (which == 6) hipLaunchKernelGGL((k_unet_conv<2, 16, 4, 1, 3>), grid, dim3(threads), lds, s, p);
+    else if (which == 5) hipLaunchKernelGGL((k_unet_conv<2, 16, 4, 1, 2>), grid, dim3(threads), lds, s, p);
     else if (which == 2) hipLaunchKernelGGL((k_unet_conv<2, 16, 4>), grid, dim3(threads), lds, s, p);
     else if (which == 4) hipLaunchKernelGGL((k_unet_conv<2, 16, 2, 2>), grid, dim3(threads), lds, s, p);
     else if (which == 1) hipLaunchKernelGGL((k_unet_conv<2, 16, 2>), grid, dim3(threads), lds, s, p);

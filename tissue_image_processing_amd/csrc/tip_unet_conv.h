@@ -133,20 +133,22 @@ __device__ __forceinline__ void uc_wait_barrier()
 // with one or two taps per chunk -- the small parity classes of the transposed convolution -- the tile issued at a chunk's first
 // tap is due one or two steps later and the wave sat on it, so those run two chunks ahead (DA = 2 needs D = 2).
 //
-// PAIR = two steps per barrier (3x3 stencils on 16-row tiles, an even number of steps).  Every barrier costs the matrix pipe a fixed
-// ~400 clocks -- the copies' issue, the first operands' way out of LDS, the counted wait, the barrier itself (clock trace) -- against
-// ~1 540 clocks of MFMA issue per step; with two steps between barriers the second step's fragment reads go out behind the first
-// step's MFMAs and that price is paid once per 48 MFMAs of a wave.  Six weight buffers: steps 2i, 2i + 1 are read, 2i + 2, 2i + 3
-// must have landed by the iteration's end, 2i + 4, 2i + 5 are issued at its start.  A pair may straddle a chunk border (nine taps
-// per chunk), so the next chunk's activations are issued at the start of the first iteration that BEGINS inside the current chunk:
-// every read of the previous chunk -- whose buffer they overwrite -- lies behind a barrier by then, and eight steps of flight remain.
-template <int NPL, int TH, int D, int DA = 1, bool PAIR = false>
+// SPB = steps per barrier (2 or 3: 3x3 stencils on 16-row tiles, the step count a multiple of SPB).  Every barrier costs the matrix
+// pipe a fixed few hundred clocks -- the copies' issue, the first operands' way out of LDS, the counted wait, the barrier itself (clock
+// trace) -- against ~1 540 clocks of MFMA issue per step; with SPB steps between barriers the later steps' fragment reads go out behind
+// the earlier steps' MFMAs and that price is paid once per SPB x 24 MFMAs of a wave.  3 SPB weight buffers: the steps of this
+// iteration are read, those of the next must have landed by its end, those of the one after are issued at its start.  An iteration
+// may straddle a chunk border (SPB = 2: nine taps per chunk), so the next chunk's activations are issued at the start of the first
+// iteration that BEGINS inside the current chunk: every read of the previous chunk -- whose buffer they overwrite -- lies behind a
+// barrier by then, and at least six steps of flight remain.
+template <int NPL, int TH, int D, int DA = 1, int SPB = 1>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer-resource builtins exist in the device pass only; the host pass needs just the stub)
     static_assert(DA == 1 || (DA == 2 && D == 2), "two-chunk activation prefetch: with the two-step weight schedule");
-    static_assert(!PAIR || (D == 4 && DA == 1 && TH == 16), "two steps per barrier: the 16-row kernel with the four-step weight schedule");
-    constexpr int UC_NBBUF = PAIR ? 6 : D + 1;
+    static_assert(SPB == 1 || ((SPB == 2 || SPB == 3) && D == 4 && DA == 1 && TH == 16), "several steps per barrier: the 16-row kernel with the four-step weight schedule");
+    constexpr bool PAIR = SPB > 1;
+    constexpr int UC_NBBUF = PAIR ? 3 * SPB : D + 1;
     constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
     static_assert(TH == 8 || (TH == 16 && NPL == 2), "16-row tiles: two pieces (LDS)");
     constexpr int A_PIECES = NPL * UC_HP * 2;
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     // prologue: activation chunk 0, weight steps 0 .. D-1
     copy_a(0, 0);
     if (DA == 2 && nchunks > 1) copy_a(1, 1);
-    for (int s0 = 0; s0 < D && s0 < nsteps; ++s0) copy_b(s0 / p.ntaps, s0 % p.ntaps, s0);
+    for (int s0 = 0; s0 < (PAIR ? 2 * SPB : D) && s0 < nsteps; ++s0) copy_b(s0 / p.ntaps, s0 % p.ntaps, s0);
     uc_wait_barrier<0>();
 
     const int r = lane & 31, h = lane >> 5;
@@ -330,30 +332,30 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     };
     if constexpr (PAIR) {
         int c0 = 0, t0 = 0;                                  // (chunk, tap) of the step about to be multiplied
-        int cb = 4 / p.ntaps, tb = 4 % p.ntaps;              // ... and of the next weight copy (four steps ahead)
-        int bb = 0;                                          // weight buffer of step 2i
+        int cb = (2 * SPB) / p.ntaps, tb = (2 * SPB) % p.ntaps;   // ... and of the next weight copy (2 SPB steps ahead)
+        int bb = 0;                                          // weight buffer of the iteration's first step
         int a_issued = 0;                                    // highest chunk whose activations are on their way (chunk 0: prologue)
         auto next = [&](int &c, int &t) { if (++t == p.ntaps) { t = 0; ++c; } };
-        auto wrap6 = [](int b) { return b >= 6 ? b - 6 : b; };
-        for (int s = 0; s < nsteps; s += 2) {
+        auto wrapb = [](int b) { return b >= UC_NBBUF ? b - UC_NBBUF : b; };
+        for (int s = 0; s < nsteps; s += SPB) {
             const bool issue_a = c0 + 1 < nchunks && c0 + 1 > a_issued;
             if (issue_a) { copy_a(c0 + 1, (c0 + 1) & 1); a_issued = c0 + 1; }
-            const bool issue_b = s + 4 < nsteps;             // (nsteps is even: then s + 5 < nsteps too)
+            const bool issue_b = s + 2 * SPB < nsteps;       // (nsteps is a multiple of SPB: then all SPB copies exist)
             if (issue_b) {
-                copy_b(cb, tb, wrap6(bb + 4)); next(cb, tb);
-                copy_b(cb, tb, wrap6(bb + 5)); next(cb, tb);
+#pragma unroll
+                for (int k = 0; k < SPB; ++k) { copy_b(cb, tb, wrapb(bb + 2 * SPB + k)); next(cb, tb); }
             }
-            buf0 = bb;
-            step_products(c0, t0);
-            next(c0, t0);
-            buf0 = wrap6(bb + 1);
-            step_products(c0, t0);
-            next(c0, t0);
-            // everything older than this iteration's copies has to be there: the weights of the next two steps (issued an iteration
-            // ago) and, when a chunk opens, its activations (issued four iterations ago)
-            if (issue_b) { if (issue_a) uc_wait_barrier<A_PER + 2 * B_PER>(); else uc_wait_barrier<2 * B_PER>(); }
+#pragma unroll
+            for (int k = 0; k < SPB; ++k) {
+                buf0 = wrapb(bb + k);
+                step_products(c0, t0);
+                next(c0, t0);
+            }
+            // everything older than this iteration's copies has to be there: the weights of the next iteration's steps (issued an
+            // iteration ago) and, when a chunk opens, its activations (issued at least two iterations ago)
+            if (issue_b) { if (issue_a) uc_wait_barrier<A_PER + SPB * B_PER>(); else uc_wait_barrier<SPB * B_PER>(); }
             else { if (issue_a) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>(); }
-            bb = wrap6(bb + 2);
+            bb = wrapb(bb + SPB);
         }
     } else
     for (int chunk = 0; chunk < nchunks; ++chunk) {
