@@ -454,6 +454,10 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
         (d->h - 1) * d->sy + d->oy >= d->out_h || (d->w - 1) * d->sx + d->ox >= d->out_w)
         return fail(TIP_ERR_ARG, "tip_unet_conv_dev: bad taps / output mapping");
     if ((d->scale == nullptr) != (d->shift == nullptr)) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: scale and shift come together");
+    // the tiles are addressed through 32-bit buffer offsets: an input's planes together have to stay below 4 GB
+    if ((long)d->planes * d->h * d->w * d->c0 * 2 >= (1L << 32) - 65536 || (long)d->planes * d->h * d->w * d->c1 * 2 >= (1L << 32) - 65536)
+        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: an input of %d x %d x %d channels x %d planes exceeds the 4 GB a buffer resource addresses",
+                    d->h, d->w, d->c0 > d->c1 ? d->c0 : d->c1, d->planes);
     ConvParams p;
     p.in0 = (const uint16_t *)d->in0; p.in1 = (const uint16_t *)(d->c1 > 0 ? d->in1 : d->in0);
     p.c0 = d->c0; p.c1 = d->c1; p.H = d->h; p.W = d->w;

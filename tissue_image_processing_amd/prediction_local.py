@@ -315,10 +315,15 @@ class _UNet(object):
         return hw
 
     def hip_path_ok(self, x):
-        """The hand-written kernels tile every level's grid in 8 x 32 pixels: extents that are multiples of 64 x 256."""
+        """The hand-written kernels tile every level's grid in 8 x 32 pixels: extents that are multiples of 64 x 256, and an
+        activation tensor has to stay below 4 GB."""
         torch = self.torch
+        planes = 2 if _unet_mode() == "bf16x3" else 3
+        # (the kernels address a layer's input through 32-bit buffer offsets: planes x H x W x 128 channels x 2 bytes < 4 GB,
+        #  i.e. frames up to 2048 x 4095 with two pieces; larger ones take the MIOpen route)
         return (_unet_mode() != "miopen" and x.is_cuda and self.dtype == torch.float32 and x.shape[0] == 1 and x.shape[1] == 2
-                and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and shares_runtime_with_torch(x))
+                and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and planes * x.shape[2] * x.shape[3] * 256 < (1 << 32) - 65536
+                and shares_runtime_with_torch(x))
 
     def _forward_hip(self, x, logits):
         torch = self.torch
