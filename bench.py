@@ -686,6 +686,9 @@ def main():
             if info.get("issued_flops_factor", 1) != 1:
                 r["issued_tflops"] = r["achieved"] * info["issued_flops_factor"]
                 r["issued_frac_of_bf16_peak"] = r["issued_tflops"] / info["issued_peak_tflops"]
+                r["note"] = ("`peak` is the nominal dense bf16 peak / 3 products; back-to-back v_mfma_f32_32x32x16_bf16 from registers with "
+                             "random operand bits sustain 1.78-1.97 PFLOP/s (71-79 % of 2.5) at a power-limited 1.77-1.93 GHz on this chip "
+                             "(tools/ubench/mfma_bf16_rate.hip, profiles/r03d_mfma_bf16_rate.txt)")
         return r
 
     from tissue_image_processing_amd import prediction_local as plm
