@@ -63,6 +63,8 @@ TIP_API int tip_sync(void);                       /* wait for this thread's stre
 /*   TIP_WS_DEBUG, TIP_WS_NO_ENDGAME, TIP_WS_NO_WIDE                                   counters / stall machinery    */
 /*   TIP_PROJECT_EXACT_SCORE, TIP_PROJECT_GENERIC, TIP_PROJECT_UNFUSED_PREBLUR, TIP_PROJECT_UNFUSED_MASK,            */
 /*   TIP_PROJECT_DEBUG, TIP_FAST_CFG = y,x, TIP_MFMA_BLOCKS_PER_CU                     projection kernel selection   */
+/*   TIP_UNET_TILE8 = -1|0|1, TIP_UNET_SPB = 1|2|3, TIP_UNET_XCD_MAP = 0|1             U-Net convolution schedule    */
+/*   TIP_UNET_TAIL_UNFUSED                                                            tail morphology as separate launches */
 /* None of them changes results: they select between schedules / kernels that are tested to agree bit for bit       */
 /* (TIP_WS_TIES = fast is the one exception and says so in `flags`).                                                */
 TIP_API int tip_set_tuning(const char *name, const char *value);

@@ -193,6 +193,11 @@ def test_network_hip_path_other_extents(shape, arith, monkeypatch):
     sep = gpu.forward(xg)
     errsep = float((sep.cpu().double() - exp).abs().max())
     dhead = float((sep - fused).abs().max())
+    monkeypatch.delenv("TISSUE_HIP_UNET_SEPARATE_HEAD")
+    # steps per barrier of the 3x3 16-row kernel (default three) and the workgroup order change the schedule, not the arithmetic
+    for knob, val in (("TIP_UNET_SPB", "1"), ("TIP_UNET_SPB", "2"), ("TIP_UNET_XCD_MAP", "0")):
+        with _lib.tuning(**{knob: val}):
+            assert torch.equal(gpu.forward(xg), fused), (knob, val)
     print("%dx%d: max |dp| %.2e (8-row tiles everywhere: %.2e, 16-row wherever possible: %.2e, separate head: %.2e, fused vs separate head %.2e)"
           % (shape[0], shape[1], err, err8, err16, errsep, dhead))
     assert err < 2e-4 and err8 < 2e-4 and err16 < 2e-4 and errsep < 2e-4 and dhead < 5e-5
