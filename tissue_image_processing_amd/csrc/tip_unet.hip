@@ -526,9 +526,9 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
         for (int k = 0; k < th / 2; ++k) {
             const unsigned long long *t = tr + 8 * k;
             const double n = (double)t[4];
-            fprintf(stderr, "UC_TRACE th %d taps %d cin %d cout %d grid %dx%d wave %d simd %d: per step (shader clocks): copies %.0f, products %.0f (first MFMA out after %.0f), "
+            fprintf(stderr, "UC_TRACE th %d spb %d taps %d cin %d cout %d grid %dx%d wave %d simd %d: per STEP (shader clocks; sums over the loop / steps): copies %.0f, products %.0f (first MFMA out after %.0f), "
                             "vmcnt wait %.0f, barrier %.0f, total %.0f; steps %.0f\n",
-                    th, d->ntaps, d->c0 + d->c1, d->cout, d->h, d->w, k, (int)((t[7] >> 4) & 3), t[0] / n, t[2] / n, t[1] / n, t[6] / n, (t[3] - t[6]) / n, t[5] / n, n);
+                    th, spb, d->ntaps, d->c0 + d->c1, d->cout, d->h, d->w, k, (int)((t[7] >> 4) & 3), t[0] / n, t[2] / n, t[1] / n, t[6] / n, (t[3] - t[6]) / n, t[5] / n, n);
         }
     }
 #endif

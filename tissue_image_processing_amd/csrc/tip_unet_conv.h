@@ -338,24 +338,34 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
         auto next = [&](int &c, int &t) { if (++t == p.ntaps) { t = 0; ++c; } };
         auto wrapb = [](int b) { return b >= UC_NBBUF ? b - UC_NBBUF : b; };
         for (int s = 0; s < nsteps; s += SPB) {
+            UC_T(t_a);
+            // The copies go out one per step, BEHIND that step's products: an asynchronous copy blocks its wave at issue while the
+            // CU's copy queue is full (clock trace: three weight copies back to back at the iteration's start held every wave for
+            // ~830 clocks), and behind the products the wave has nothing else to do before the barrier anyway.  Their order relative
+            // to the iteration's wait is what the counted wait relies on, and that does not change.
             const bool issue_a = c0 + 1 < nchunks && c0 + 1 > a_issued;
-            if (issue_a) { copy_a(c0 + 1, (c0 + 1) & 1); a_issued = c0 + 1; }
+            const int ca = c0 + 1;
+            if (issue_a) a_issued = ca;
             const bool issue_b = s + 2 * SPB < nsteps;       // (nsteps is a multiple of SPB: then all SPB copies exist)
-            if (issue_b) {
-#pragma unroll
-                for (int k = 0; k < SPB; ++k) { copy_b(cb, tb, wrapb(bb + 2 * SPB + k)); next(cb, tb); }
-            }
+            UC_T(t_b);
 #pragma unroll
             for (int k = 0; k < SPB; ++k) {
                 buf0 = wrapb(bb + k);
                 step_products(c0, t0);
                 next(c0, t0);
+                if (k == 0 && issue_a) copy_a(ca, ca & 1);
+                if (issue_b) { copy_b(cb, tb, wrapb(bb + 2 * SPB + k)); next(cb, tb); }
             }
+            UC_T(t_c);
             // everything older than this iteration's copies has to be there: the weights of the next iteration's steps (issued an
             // iteration ago) and, when a chunk opens, its activations (issued at least two iterations ago)
-            if (issue_b) { if (issue_a) uc_wait_barrier<A_PER + SPB * B_PER>(); else uc_wait_barrier<SPB * B_PER>(); }
-            else { if (issue_a) uc_wait_barrier<A_PER>(); else uc_wait_barrier<0>(); }
+            if (issue_b) { if (issue_a) UC_WB<A_PER + SPB * B_PER>(); else UC_WB<SPB * B_PER>(); }
+            else { if (issue_a) UC_WB<A_PER>(); else UC_WB<0>(); }
             bb = wrapb(bb + SPB);
+#ifdef UC_TRACE
+            UC_T(t_d);
+            tr_copy += t_b - t_a; tr_mfma += t_c - t_b; tr_bar += t_d - t_c; tr_wait += t_w - t_c;
+#endif
         }
     } else
     for (int chunk = 0; chunk < nchunks; ++chunk) {
