@@ -374,10 +374,11 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             // copies: the next chunk's activations at the chunk's first tap, the weights of step + D
             const bool issue_a = tap == 0 && chunk + DA < nchunks;
             const bool issue_b = step + D < nsteps;
-            if (issue_a) copy_a(chunk + DA, (chunk + DA) % (DA + 1));
-            if (issue_b) copy_b(nc, nt, buf2);
             UC_T(t_b);
             step_products(chunk, tap);
+            // (behind the products: a copy blocks its wave at issue while the copy queue is full, see the loop above)
+            if (issue_a) copy_a(chunk + DA, (chunk + DA) % (DA + 1));
+            if (issue_b) copy_b(nc, nt, buf2);
             if (++nt == p.ntaps) { nt = 0; ++nc; }
             UC_T(t_c);
             // Before the barrier the weights of step + 1 must have landed (issued one step ago, before everything issued in
