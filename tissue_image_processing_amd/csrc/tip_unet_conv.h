@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             const int hy = px / UC_HW, hx = px - hy * UC_HW;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            a_off[u] = inside ? (unsigned)((pl * plane_stride + ((long)gy * p.W + gx) * C + half * 8) * 2) : 0xfffffff0u;
+            a_off[u] = inside ? (unsigned)((pl * plane_stride + ((long)gy * p.W + gx) * C + half * 8) * 2) : 0xffff0000u;     // (beyond any admissible extent -- the launcher keeps tensors below 2^32 - 65536 bytes -- and the step's scalar offset cannot wrap it around)
         }
     };
     plan_a(p.c0, in_plane0);
