@@ -471,8 +471,8 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     p.pool_out = (uint16_t *)d->pool_out;
 #ifdef UC_TRACE
     static unsigned long long *trace_dev = nullptr;
-    if (!trace_dev) { TIP_HIP(hipMalloc(&trace_dev, 512)); }
-    TIP_HIP(hipMemsetAsync(trace_dev, 0, 512, (hipStream_t)stream));
+    if (!trace_dev) { TIP_HIP(hipMalloc(&trace_dev, 1024)); }
+    TIP_HIP(hipMemsetAsync(trace_dev, 0, 1024, (hipStream_t)stream));
     p.trace = trace_dev;
 #endif
     p.head_w = d->head_w; p.head_b = d->head_b; p.head_out = d->head_out;
@@ -520,15 +520,15 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     else hipLaunchKernelGGL((k_unet_conv<2, 8, 2>), grid, dim3(threads), lds, s, p);
 #ifdef UC_TRACE
     {
-        unsigned long long tr[64];
+        unsigned long long tr[128];
         TIP_HIP(hipStreamSynchronize(s));
         TIP_HIP(hipMemcpy(tr, trace_dev, sizeof tr, hipMemcpyDeviceToHost));
         for (int k = 0; k < th / 2; ++k) {
-            const unsigned long long *t = tr + 8 * k;
+            const unsigned long long *t = tr + 16 * k;
             const double n = (double)t[4];
             fprintf(stderr, "UC_TRACE th %d spb %d taps %d cin %d cout %d grid %dx%d wave %d simd %d: per STEP (shader clocks; sums over the loop / steps): copies %.0f, products %.0f (first MFMA out after %.0f), "
-                            "vmcnt wait %.0f, barrier %.0f, total %.0f; steps %.0f\n",
-                    th, spb, d->ntaps, d->c0 + d->c1, d->cout, d->h, d->w, k, (int)((t[7] >> 4) & 3), t[0] / n, t[2] / n, t[1] / n, t[6] / n, (t[3] - t[6]) / n, t[5] / n, n);
+                            "vmcnt wait %.0f, barrier %.0f, total %.0f; steps %.0f; whole loop %.0f, prologue %.0f, epilogue %.0f clocks\n",
+                    th, spb, d->ntaps, d->c0 + d->c1, d->cout, d->h, d->w, k, (int)((t[7] >> 4) & 3), t[0] / n, t[2] / n, t[1] / n, t[6] / n, (t[3] - t[6]) / n, t[5] / n, n, (double)t[5], (double)t[8], (double)t[9]);
         }
     }
 #endif

@@ -145,6 +145,9 @@ template <int NPL, int TH, int D, int DA = 1, int SPB = 1>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer-resource builtins exist in the device pass only; the host pass needs just the stub)
+#ifdef UC_TRACE
+    const unsigned long long tr_enter = __builtin_amdgcn_s_memtime();
+#endif
     static_assert(DA == 1 || (DA == 2 && D == 2), "two-chunk activation prefetch: with the two-step weight schedule");
     static_assert(SPB == 1 || ((SPB == 2 || SPB == 3) && D == 4 && DA == 1 && TH == 16), "several steps per barrier: the 16-row kernel with the four-step weight schedule");
     constexpr bool PAIR = SPB > 1;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     // clock sums over the main loop for ONE wave (block 0, wave 0): [0] copies issued, [1] fragment reads issued .. first operands
     // there (inside step_products), [2] products issued, [3] wait + barrier, [4] steps, [5] loop total
     unsigned long long tr_copy = 0, tr_read = 0, tr_mfma = 0, tr_bar = 0, tr_t0 = __builtin_amdgcn_s_memtime();
-    const bool tracing = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool tracing = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;      // (a workgroup in the middle of the launch: warm caches, busy chip)
     unsigned long long tr_wait = 0, t_w = 0;
 #define UC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define UC_WB t_w = uc_wait_barrier_timed
@@ -416,10 +419,12 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     }
 #ifdef UC_TRACE
     if (tracing && p.trace && lane == 0) {
-        unsigned long long *tp = p.trace + 8 * wave;
+        unsigned long long *tp = p.trace + 16 * wave;
         tp[0] = tr_copy; tp[1] = tr_read; tp[2] = tr_mfma; tp[3] = tr_bar; tp[4] = (unsigned long long)nsteps;
         tp[5] = __builtin_amdgcn_s_memtime() - tr_t0; tp[6] = tr_wait; tp[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tp[8] = tr_t0 - tr_enter;              // set-up + prologue (first tiles on their way and landed)
     }
+    const unsigned long long tr_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 #undef UC_PRODUCT
 
@@ -584,6 +589,12 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             }
         }
     }
+#ifdef UC_TRACE
+    if (tracing && p.trace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores accepted: what a following workgroup would wait for)
+        p.trace[16 * wave + 9] = __builtin_amdgcn_s_memtime() - tr_loop_end;
+    }
+#endif
 #endif
 }
 
