@@ -72,6 +72,31 @@ def test_label_large_vs_oracle(env):
     np.testing.assert_array_equal(out, ref)
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (65, 97), (300, 421), (700, 900), (2048, 2048)])
+def test_tiled_union_find_equals_one_level(env, shape):
+    """Connected components by tiles in LDS + a border pass (the default from 64 x 64 pixels on) against the one-level union-find
+    on global memory and the oracle: blobs that span many tiles, a spiral that crosses every tile border many times, noise; the
+    raster-order numbering (roots = raster-first pixels) has to survive both levels."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    a = (rng.random(shape) > 0.45).astype(np.int32)
+    a[(np.sin(yy / 9.0) * np.cos(xx / 13.0)) > 0.3] = 1                     # blobs of a few hundred to a few thousand pixels
+    r = np.hypot(yy - shape[0] / 2, xx - shape[1] / 2)
+    a[(np.floor(r + 4 * np.arctan2(yy - shape[0] / 2, xx - shape[1] / 2) / np.pi) % 8) == 0] = 1   # a spiral arm
+    a[::11, ::3] = 0
+    out, n = seg.label(a, background=0, return_num=True, connectivity=1)
+    with _lib.tuning(TIP_UF_ONE_LEVEL="1"):
+        out1, n1 = seg.label(a, background=0, return_num=True, connectivity=1)
+    assert n == n1
+    np.testing.assert_array_equal(out, out1)
+    if shape[0] * shape[1] <= 700 * 900:
+        ref, n_ref = orc.label4(a, 0)
+        assert n == n_ref
+        np.testing.assert_array_equal(out, ref)
+
+
 @pytest.mark.parametrize("case", ["ii", "iii", "iv"])
 def test_watershed_float_golden_bit_exact(env, golden, case):
     """Distinct-valued float landscapes: labels identical to skimage's serial flood."""

@@ -67,6 +67,7 @@ struct Tuning {
     int unet_tail_unfused = 0;  // TIP_UNET_TAIL_UNFUSED: the tail's morphology as separate rank-filter launches (tests)
     int unet_xcd_map = 1;       // TIP_UNET_XCD_MAP: the channel blocks of one pixel tile side by side on one XCD (0: all workgroups in flight on one channel block)
     int unet_spb = 3;           // TIP_UNET_SPB: steps per barrier of the 3x3 16-row convolution kernel (1, 2 or 3)
+    int uf_one_level = 0;       // TIP_UF_ONE_LEVEL: the one-level union-find (global atomics only) instead of tiles in LDS + borders (tests)
     int unet_tile8 = -1;        // TIP_UNET_TILE8: the U-Net convolution's tile rows: 1 = 8 everywhere, 0 = 16 where the grid allows, -1 (default) = 16 except for 3x3 layers with <= 128 input channels
 };
 const Tuning &tuning();
