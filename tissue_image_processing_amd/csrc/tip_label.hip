@@ -73,6 +73,28 @@ __global__ void __launch_bounds__(1024) k_scan_sums(int *__restrict__ bsum, int 
     if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// ... with the scan of the block sums folded in (few blocks: every block adds up the sums in front of it itself -- one launch less;
+// the last block writes the total)
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add_own(int *__restrict__ out, long n, const int *__restrict__ bsum, int nb,
+                                                               int *__restrict__ total)
+{
+    __shared__ int wsum[SCAN_THREADS / 64];
+    int s = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) s += bsum[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) off += wsum[w];
+    if (total && (int)blockIdx.x == nb - 1 && threadIdx.x == 0) *total = off + bsum[nb - 1];
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) out[base + i] += off;
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int *__restrict__ out, long n, const int *__restrict__ bsum)
 {
     const int off = bsum[blockIdx.x];
@@ -89,6 +111,10 @@ int exclusive_scan_i32(const int *in, int *out, long n, int *total_dev)
     int *bsum = ws.get<int>(nb);
     if (!bsum) return TIP_ERR_NOMEM;
     TIP_LAUNCH("scan_block", k_scan_block, dim3(nb), dim3(SCAN_THREADS), 0, in, out, n, bsum);
+    if (nb <= 4096) {          // (up to 8.4 M elements: a block reads at most 16 KB of block sums out of L2)
+        TIP_LAUNCH("scan_add_own", k_scan_add_own, dim3(nb), dim3(SCAN_THREADS), 0, out, n, (const int *)bsum, nb, total_dev);
+        return TIP_OK;
+    }
     TIP_LAUNCH("scan_sums", k_scan_sums, dim3(1), dim3(1024), 0, bsum, nb, total_dev);
     TIP_LAUNCH("scan_add", k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, out, n, (const int *)bsum);
     return TIP_OK;
