@@ -146,10 +146,13 @@ TIP_API int tip_bias_relu_affine_f32_dev(float *x, const float *bias, const floa
 TIP_API int tip_pointer_device(const void *p);
 TIP_API int tip_wait_stream(void *stream);
 TIP_API int tip_stream_wait_tip(void *stream);
-/* ---- the U-Net's layers (pl.py:31-72) on the bf16 matrix cores with split float32 operands --------------------- */
-/* Activations between layers are `planes` (2 or 3) bf16 images [plane][y][x][channel] whose sum is the float32 value */
-/* (csrc/tip_unet_conv.h has the arithmetic and its error bound).  Every call launches on `stream` (torch's current  */
-/* stream: the buffers are torch tensors) and returns at once.                                                        */
+/* ---- the U-Net's layers (pl.py:31-72) on the 16-bit matrix cores with split float32 operands ------------------- */
+/* Activations between layers are `planes` 16-bit images [plane][y][x][channel] whose sum is the float32 value:       */
+/* format 0 = bf16 pieces (planes 2: three products per term, 2^-16; planes 3: six products, float32-equivalent),      */
+/* format 1 = fp16 pieces (planes 2) of values SCALED by a power of two: three products per term, float32-equivalent   */
+/* to 2^-21 (csrc/tip_unet_conv.h has the arithmetic and its error bound).  Every call launches on `stream` (torch's   */
+/* current stream: the buffers are torch tensors) and returns at once.  Tensors may be of any size (a tile's halo      */
+/* window, 18 rows of one plane, has to stay below 4 GB).                                                              */
 typedef struct tip_unet_conv_desc {
     const void *in0, *in1;      /* split activations; in1 (c1 channels) is appended to in0's channels: concatenate   */
     int c0, c1, h, w, planes;   /* channels (multiples of 16), input grid (multiples of 8 x 32), pieces per value     */
@@ -164,15 +167,17 @@ typedef struct tip_unet_conv_desc {
                                 /* the same registers (Conv2D -> MaxPool2D, pl.py:42-43); needs sy = sx = 1, oy = ox = 0   */
     const float *head_w, *head_b; /* NULL, or the network's head fused into this layer (cout == 128, plain mapping, BN present):  */
     float *head_out;            /* Conv2D(128 -> 2, 1x1) weights [2][128], bias [2], softmax -> float32 (2, h, w); `out` unused    */
+    int format;                 /* 0: bf16 pieces; 1: fp16 pieces (planes == 2) -- activations, weights and the constants carry the  */
+    float acc_scale;            /* caller's power-of-two scales, and the accumulator is multiplied by acc_scale before the bias      */
 } tip_unet_conv_desc;
 TIP_API int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream);
 /* first layer, Conv2D(2 -> 128): float32 (2, h, w) in, weights [9][2][128] float32, exact float32 FMAs               */
 TIP_API int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, const float *bias, const float *scale,
-                                    const float *shift, void *out, int planes, void *stream);
-TIP_API int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, void *out, void *stream);   /* MaxPool2D(2) */
+                                    const float *shift, void *out, int planes, int format, void *stream);
+TIP_API int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, int format, void *out, void *stream);   /* MaxPool2D(2) */
 /* Conv2D(128 -> 2, 1x1) + softmax: float32 (2, npix) out; logits != 0: the pre-softmax values                         */
-TIP_API int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int logits,
-                              void *stream);
+TIP_API int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int format,
+                              int logits, void *stream);
 /* U1, prepare_image + normalize_channel (pl.py:21-29, 90-122) on a device-resident image: img = (c, a, b) float64,       */
 /* element strides (cstride, sa, sb), every channel plane dense in either orientation; kind = dtype of the caller's image  */
 /* (0 float64, 1 float32, 2 integer: the clip values take it, pl.py:26-27).  Per channel: np.percentile 1 / 99 (exact order  */

@@ -10,7 +10,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtissue_hip.so")
+# TISSUE_HIP_LIB: another build of the same library (diagnostic builds, tools/unet_trace.sh); never a different implementation
+LIB_PATH = os.environ.get("TISSUE_HIP_LIB") or os.path.join(_HERE, "libtissue_hip.so")
 _lib = None
 _lock = threading.Lock()
 _tls = threading.local()

@@ -9,6 +9,7 @@
 #include "tip_internal.h"
 #include "tip_unet_conv.h"
 #include <algorithm>
+#include <atomic>
 
 namespace tip {
 
@@ -446,6 +447,8 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     if (!c.stream) return TIP_ERR_HIP;
     if (!d || !d->in0 || !d->weights || !d->bias || (!d->out && !d->head_out)) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: null pointer");
     if (d->planes != 2 && d->planes != 3) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: planes must be 2 or 3");
+    if (d->format != 0 && d->format != 1) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: format is 0 (bf16 pieces) or 1 (fp16 pieces)");
+    if (d->format == 1 && (d->planes != 2 || !(d->acc_scale > 0.f))) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: fp16 pieces come in two planes with a positive acc_scale");
     if (d->h < 8 || d->w < UC_TW || d->h % 8 || d->w % UC_TW)
         return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: the grid %dx%d is not a multiple of the 8x%d pixel tile", d->h, d->w, UC_TW);
     if (d->c0 < UC_KC || d->c0 % UC_KC || d->c1 < 0 || d->c1 % UC_KC || (d->c1 > 0 && !d->in1) || d->cout < UC_BN || d->cout % UC_BN)
@@ -454,10 +457,10 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
         (d->h - 1) * d->sy + d->oy >= d->out_h || (d->w - 1) * d->sx + d->ox >= d->out_w)
         return fail(TIP_ERR_ARG, "tip_unet_conv_dev: bad taps / output mapping");
     if ((d->scale == nullptr) != (d->shift == nullptr)) return fail(TIP_ERR_ARG, "tip_unet_conv_dev: scale and shift come together");
-    // the tiles are addressed through 32-bit buffer offsets: an input's planes together have to stay below 4 GB
-    if ((long)d->planes * d->h * d->w * d->c0 * 2 >= (1L << 32) - 65536 || (long)d->planes * d->h * d->w * d->c1 * 2 >= (1L << 32) - 65536)
-        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: an input of %d x %d x %d channels x %d planes exceeds the 4 GB a buffer resource addresses",
-                    d->h, d->w, d->c0 > d->c1 ? d->c0 : d->c1, d->planes);
+    // a tile's halo window ((tile rows + 2) image rows of one plane) is addressed through 32-bit buffer offsets; tensors may be any size
+    if (18L * d->w * (d->c0 > d->c1 ? d->c0 : d->c1) * 2 >= (1L << 32) - 65536)
+        return fail(TIP_ERR_UNSUPPORTED, "tip_unet_conv_dev: 18 rows of %d pixels x %d channels exceed the 4 GB a buffer resource addresses",
+                    d->w, d->c0 > d->c1 ? d->c0 : d->c1);
     ConvParams p;
     p.in0 = (const uint16_t *)d->in0; p.in1 = (const uint16_t *)(d->c1 > 0 ? d->in1 : d->in0);
     p.c0 = d->c0; p.c1 = d->c1; p.H = d->h; p.W = d->w;
@@ -469,6 +472,7 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     p.cout = d->cout; p.bias = d->bias; p.scale = d->scale; p.shift = d->shift;
     p.out = (uint16_t *)d->out; p.outH = d->out_h; p.outW = d->out_w; p.sy = d->sy; p.sx = d->sx; p.oy = d->oy; p.ox = d->ox;
     p.pool_out = (uint16_t *)d->pool_out;
+    p.acc_scale = d->format == 1 ? d->acc_scale : 1.f;
 #ifdef UC_TRACE
     static unsigned long long *trace_dev = nullptr;
     if (!trace_dev) { TIP_HIP(hipMalloc(&trace_dev, 1024)); }
@@ -494,7 +498,7 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     const int ntiles = (d->h / th) * (d->w / UC_TW), nblks = d->cout / UC_BN;
     p.xcd_map = (tuning().unet_xcd_map && nblks > 1 && ntiles % 8 == 0) ? 1 : 0;
     const dim3 grid = p.xcd_map ? dim3((unsigned)(ntiles * nblks)) : dim3(ntiles, nblks);
-    const int a_per = (d->planes * hp * 2 + threads - 1) / threads;
+    const int a_per = (d->planes * ((hp * 2 + 63) / 64) * 64 + threads - 1) / threads;     // (a plane's halo tile padded to whole waves, as in the kernel)
     // several steps per barrier: 3x3 stencils on 16-row tiles; three (a chunk's nine taps in three iterations, nine weight buffers)
     // or two (six buffers; needs an even number of steps)
     const int spb_want = tuning().unet_spb;
@@ -502,22 +506,40 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     const int spb = !multi ? 1 : (spb_want >= 3 ? 3 : ((((d->c0 + d->c1) / UC_KC) & 1) == 0 ? 2 : 1));
     const size_t lds = (size_t)(da + 1) * a_per * threads * 16 + (size_t)(spb > 1 ? 3 * spb : dist + 1) * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set[7] = {false, false, false, false, false, false, false};
     const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? (spb == 3 ? 6 : (spb == 2 ? 5 : 2)) : (da == 2 ? 4 : 1)) : 0);
-    const void *fn = which == 3 ? (const void *)k_unet_conv<3, 8, 2>
-                   : which == 6 ? (const void *)k_unet_conv<2, 16, 4, 1, 3>
-                   : which == 5 ? (const void *)k_unet_conv<2, 16, 4, 1, 2>
-                   : which == 2 ? (const void *)k_unet_conv<2, 16, 4>
-                   : which == 4 ? (const void *)k_unet_conv<2, 16, 2, 2>
-                   : which == 1 ? (const void *)k_unet_conv<2, 16, 2> : (const void *)k_unet_conv<2, 8, 2>;
-    if (!attr_set[which]) { TIP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[which] = true; }
-    if (which == 3) hipLaunchKernelGGL((k_unet_conv<3, 8, 2>), grid, dim3(threads), lds, s, p);
-    else if (which == 6) hipLaunchKernelGGL((k_unet_conv<2, 16, 4, 1, 3>), grid, dim3(threads), lds, s, p);
-    else if (which == 5) hipLaunchKernelGGL((k_unet_conv<2, 16, 4, 1, 2>), grid, dim3(threads), lds, s, p);
-    else if (which == 2) hipLaunchKernelGGL((k_unet_conv<2, 16, 4>), grid, dim3(threads), lds, s, p);
-    else if (which == 4) hipLaunchKernelGGL((k_unet_conv<2, 16, 2, 2>), grid, dim3(threads), lds, s, p);
-    else if (which == 1) hipLaunchKernelGGL((k_unet_conv<2, 16, 2>), grid, dim3(threads), lds, s, p);
-    else hipLaunchKernelGGL((k_unet_conv<2, 8, 2>), grid, dim3(threads), lds, s, p);
+    // the >64 KB dynamic LDS attribute is set once per (device, kernel): one atomic bit each
+    static std::atomic<unsigned> attr_done[64];
+    const unsigned bit = 1u << (which + (d->format ? 8 : 0));
+    const int dev = c.device >= 0 && c.device < 64 ? c.device : 0;
+#define UC_FLAVOUR(W, ...)                                                                                                                  \
+    case W: {                                                                                                                               \
+        if (!(attr_done[dev].load(std::memory_order_acquire) & bit)) {                                                                      \
+            TIP_HIP(hipFuncSetAttribute((const void *)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+            attr_done[dev].fetch_or(bit, std::memory_order_release);                                                                        \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(threads), lds, s, p);                                                                  \
+    } break;
+    if (d->format == 0) {
+        switch (which) {
+            UC_FLAVOUR(3, k_unet_conv<3, 8, 2>)
+            UC_FLAVOUR(6, k_unet_conv<2, 16, 4, 1, 3>)
+            UC_FLAVOUR(5, k_unet_conv<2, 16, 4, 1, 2>)
+            UC_FLAVOUR(2, k_unet_conv<2, 16, 4>)
+            UC_FLAVOUR(4, k_unet_conv<2, 16, 2, 2>)
+            UC_FLAVOUR(1, k_unet_conv<2, 16, 2>)
+            UC_FLAVOUR(0, k_unet_conv<2, 8, 2>)
+        }
+    } else {
+        switch (which) {
+            UC_FLAVOUR(6, k_unet_conv<2, 16, 4, 1, 3, true>)
+            UC_FLAVOUR(5, k_unet_conv<2, 16, 4, 1, 2, true>)
+            UC_FLAVOUR(2, k_unet_conv<2, 16, 4, 1, 1, true>)
+            UC_FLAVOUR(4, k_unet_conv<2, 16, 2, 2, 1, true>)
+            UC_FLAVOUR(1, k_unet_conv<2, 16, 2, 1, 1, true>)
+            UC_FLAVOUR(0, k_unet_conv<2, 8, 2, 1, 1, true>)
+        }
+    }
+#undef UC_FLAVOUR
 #ifdef UC_TRACE
     {
         unsigned long long tr[128];
@@ -536,40 +558,45 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
 }
 
 int tip_unet_conv_first_dev(const float *in, int h, int w, const float *wgt, const float *bias, const float *scale, const float *shift,
-                            void *out, int planes, void *stream)
+                            void *out, int planes, int format, void *stream)
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || w % FIRST_RUN || ((long)h * w) % FIRST_PIX || (planes != 2 && planes != 3))
+    if (!in || !wgt || !bias || !scale || !shift || !out || h < 1 || w < 1 || w % FIRST_RUN || ((long)h * w) % FIRST_PIX || (planes != 2 && planes != 3) ||
+        (format != 0 && !(format == 1 && planes == 2)))
         return fail(TIP_ERR_ARG, "tip_unet_conv_first_dev: bad arguments (w must be a multiple of 32, h * w of 256)");
     const dim3 grid((unsigned)((long)h * w / FIRST_PIX));
     hipStream_t s = (hipStream_t)stream;
-    if (planes == 2) hipLaunchKernelGGL(k_unet_conv_first<2>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
+    if (format == 1) hipLaunchKernelGGL((k_unet_conv_first<2, true>), grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
+    else if (planes == 2) hipLaunchKernelGGL(k_unet_conv_first<2>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
     else hipLaunchKernelGGL(k_unet_conv_first<3>, grid, dim3(256), 0, s, in, h, w, wgt, bias, scale, shift, (uint16_t *)out);
     return unet_launch_check("unet_conv_first");
 }
 
-int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, void *out, void *stream)
+int tip_unet_pool2_dev(const void *in, int h, int w, int ch, int planes, int format, void *out, void *stream)
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!in || !out || h < 2 || w < 2 || (h & 1) || (w & 1) || ch < 8 || ch % 8 || (planes != 2 && planes != 3))
+    if (!in || !out || h < 2 || w < 2 || (h & 1) || (w & 1) || ch < 8 || ch % 8 || (planes != 2 && planes != 3) || (format != 0 && !(format == 1 && planes == 2)))
         return fail(TIP_ERR_ARG, "tip_unet_pool2_dev: bad arguments");
     const long n = (long)(h / 2) * (w / 2) * (ch / 8);
     hipStream_t s = (hipStream_t)stream;
-    if (planes == 2) hipLaunchKernelGGL(k_unet_pool2<2>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
+    if (format == 1) hipLaunchKernelGGL((k_unet_pool2<2, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
+    else if (planes == 2) hipLaunchKernelGGL(k_unet_pool2<2>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
     else hipLaunchKernelGGL(k_unet_pool2<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint16_t *)in, h, w, ch, (uint16_t *)out);
     return unet_launch_check("unet_pool2");
 }
 
-int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int logits, void *stream)
+int tip_unet_head_dev(const void *in, long npix, const float *wgt, const float *bias, float *out, int planes, int format, int logits, void *stream)
 {
     Ctx &c = ctx();
     if (!c.stream) return TIP_ERR_HIP;
-    if (!in || !wgt || !bias || !out || npix < 1 || (planes != 2 && planes != 3)) return fail(TIP_ERR_ARG, "tip_unet_head_dev: bad arguments");
+    if (!in || !wgt || !bias || !out || npix < 1 || (planes != 2 && planes != 3) || (format != 0 && !(format == 1 && planes == 2)))
+        return fail(TIP_ERR_ARG, "tip_unet_head_dev: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(cdiv(npix * 8, 256));
-    if (planes == 2) hipLaunchKernelGGL(k_unet_head<2>, grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
+    if (format == 1) hipLaunchKernelGGL((k_unet_head<2, true>), grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
+    else if (planes == 2) hipLaunchKernelGGL(k_unet_head<2>, grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
     else hipLaunchKernelGGL(k_unet_head<3>, grid, dim3(256), 0, s, (const uint16_t *)in, npix, wgt, bias, out, logits);
     return unet_launch_check("unet_head");
 }

@@ -39,6 +39,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float UC_F16_MAX = 65504.f;          // largest finite fp16: scaled activations saturate there (see "piece formats")
 
 constexpr int UC_TW = 32;                     // pixel tile: TH rows (8 or 16: template parameter) x 32 columns
 constexpr int UC_BN = 128;                    // output channels per workgroup
@@ -62,6 +65,7 @@ struct ConvParams {
     unsigned long long *trace;     // diagnostic build: clock sums of block 0 / wave 0 (tools/unet_trace.py)
 #endif
     int xcd_map;                   // workgroup -> (tile, channel block) mapping, see the kernel
+    float acc_scale;               // fp16 pieces: the accumulator is multiplied by this (1 / (activation scale x weight scale), a power of two) before the bias
     uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
@@ -89,6 +93,54 @@ __device__ __forceinline__ float fmax_pair(float v)
 }
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// Piece formats.  F16 == false: bf16 pieces (8 significand bits each; NPL = 2: three products per term, <= 2^-15.9 dropped; NPL = 3:
+// six products, float32-equivalent).  F16 == true: fp16 pieces (11 significand bits each) of SCALED values -- hi = fp16(s v),
+// lo = fp16(s v - hi): |s v - hi - lo| <= 2^-22 |s v| while lo is a normal fp16 number, and an ABSOLUTE 2^-25 / s below that (fp16
+// subnormals are kept by v_cvt_f16_f32 and by the matrix core) -- so the same three products hi hi + hi lo + lo hi drop <= 3 x 2^-22
+// of a term: float32-equivalent at the bf16x3 cost.  The price is fp16's range: s v has to stay below 65504.  Activations are
+// stored with s = 2^4 (they saturate beyond |v| = 4094; the absolute floor is 2^-29), every layer's weights with their own power of
+// two that puts the largest one in [2^14, 2^15); the accumulator is multiplied by acc_scale = 1 / (both) -- all powers of two, so
+// the scaling itself is exact.
+template <bool F16>
+__device__ __forceinline__ f32x16 uc_mfma(const uint4 &a, const uint4 &b, const f32x16 &c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// rounds (a, b) to the next piece (nearest even) and keeps the remainders when more pieces follow; returns the packed word
+template <bool F16>
+__device__ __forceinline__ unsigned uc_piece_word(float &a, float &b, bool more)
+{
+    if constexpr (F16) {
+        f16x2 hv;
+        hv[0] = (_Float16)a;
+        hv[1] = (_Float16)b;
+        if (more) {
+            a -= (float)hv[0];
+            b -= (float)hv[1];
+        }
+        return __builtin_bit_cast(unsigned, hv);
+    } else {
+        bf16x2 hv;
+        hv[0] = (__bf16)a;
+        hv[1] = (__bf16)b;
+        const unsigned w = __builtin_bit_cast(unsigned, hv);
+        if (more) {
+            const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+            a = r[0];
+            b = r[1];
+        }
+        return w;
+    }
+}
+template <bool F16>
+__device__ __forceinline__ float uc_piece_value(unsigned halfword)
+{
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)halfword);
+    else return __uint_as_float(halfword << 16);
+}
+__device__ __forceinline__ float uc_sat_f16(float v) { return __builtin_amdgcn_fmed3f(v, -UC_F16_MAX, UC_F16_MAX); }
 
 // A counted wait on the vector-memory queue followed by the workgroup barrier.  The asynchronous global -> LDS copies of
 // LATER steps stay in flight across the barrier (a __syncthreads() would drain them: its fence waits for vmcnt(0) while an
@@ -141,7 +193,7 @@ __device__ __forceinline__ void uc_wait_barrier()
 // may straddle a chunk border (SPB = 2: nine taps per chunk), so the next chunk's activations are issued at the start of the first
 // iteration that BEGINS inside the current chunk: every read of the previous chunk -- whose buffer they overwrite -- lies behind a
 // barrier by then, and at least six steps of flight remain.
-template <int NPL, int TH, int D, int DA = 1, int SPB = 1>
+template <int NPL, int TH, int D, int DA = 1, int SPB = 1, bool F16 = false>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer-resource builtins exist in the device pass only; the host pass needs just the stub)
@@ -154,8 +206,10 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     constexpr int UC_NBBUF = PAIR ? 3 * SPB : D + 1;
     constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
     static_assert(TH == 8 || (TH == 16 && NPL == 2), "16-row tiles: two pieces (LDS)");
-    constexpr int A_PIECES = NPL * UC_HP * 2;
-    constexpr int A_PER = (A_PIECES + UC_THREADS - 1) / UC_THREADS;      // copy instructions per thread and chunk (6 / 8)
+    // a plane's halo tile is padded to whole waves of slots (A_PLANE): one copy instruction of one wave then serves ONE plane, and
+    // the plane picks the buffer resource (scalar) instead of adding a plane stride to the 32-bit per-lane offset
+    constexpr int A_GPP = (UC_HP * 2 + 63) / 64, A_PLANE = A_GPP * 64;    // wave-groups / slots per plane (20 / 1280 for 16 rows, 11 / 704 for 8)
+    constexpr int A_PER = (NPL * A_PLANE + UC_THREADS - 1) / UC_THREADS;  // copy instructions per thread and chunk (5 / 6 / 9)
     constexpr int A_SLOTS = A_PER * UC_THREADS;                           // padded: every wave issues the same number of copies
     constexpr int A_BYTES = A_SLOTS * 16;
     constexpr int B_PER = NPL * 256 / UC_THREADS;                         // weight slots per thread (NPL * 256 slots)
@@ -185,6 +239,8 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     const int ty0 = (tile / tilesX) * TH, tx0 = (tile % tilesX) * UC_TW;
     const int cin = p.c0 + p.c1, nchunks = cin / UC_KC, nsteps = nchunks * p.ntaps;
     const long in_plane0 = (long)p.H * p.W * p.c0, in_plane1 = (long)p.H * p.W * p.c1;
+    const int rowbase = ty0 > 0 ? ty0 - 1 : 0;                // first image row of the halo window
+    const int winrows = min(p.H, ty0 + TH + 1) - rowbase;     // ... and its rows inside the image
 
     // ---- copy plans (fixed per thread) ------------------------------------------------------------------------------------
     // The tiles arrive by buffer_load_dwordx4 ... lds: a buffer resource (scalar registers: base, extent) + a per-lane byte offset
@@ -193,40 +249,51 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     // showed every step opening with ~210 clocks of copy addressing in all waves, during which the matrix pipe had nothing to
     // issue, and vector instructions of one wave also delay its SIMD partner's MFMAs.  Halo pixels outside the image (and the
     // padding slots) carry an offset beyond the resource's extent: the hardware's range check returns zeros for them.
-    // activation slot q = u * THREADS + tid: plane, halo pixel, stored half -> image pixel and logical half
+    // activation slot q = u * THREADS + tid = group g = u * (THREADS / 64) + wave (scalar), lane: plane g / A_GPP, slot inside the plane
+    // -> halo pixel, stored half -> image pixel and logical half.  The buffer resource of a copy covers ONE plane's halo WINDOW (the
+    // image rows rowbase .. rowbase + winrows - 1 of the input: <= (TH + 2) W C 2 bytes), so tensors of any size are addressed with
+    // 32-bit offsets relative to the window.
     unsigned a_off[A_PER];
-    auto plan_a = [&](int C, long plane_stride) {
+    auto plan_a = [&](int C) {
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
-            const int q = u * UC_THREADS + tid;
-            const int pl = q / (UC_HP * 2), rem = q - pl * (UC_HP * 2), px = rem >> 1, half = (rem & 1) ^ ((px >> 3) & 1);
+            const int g = u * (UC_THREADS / 64) + wave, pl = g / A_GPP;
+            const int rem = (g - pl * A_GPP) * 64 + lane, px = rem >> 1, half = (rem & 1) ^ ((px >> 3) & 1);
             const int hy = px / UC_HW, hx = px - hy * UC_HW;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            const bool inside = q < A_PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            a_off[u] = inside ? (unsigned)((pl * plane_stride + ((long)gy * p.W + gx) * C + half * 8) * 2) : 0xffff0000u;     // (beyond any admissible extent -- the launcher keeps tensors below 2^32 - 65536 bytes -- and the step's scalar offset cannot wrap it around)
+            const bool inside = pl < NPL && rem < UC_HP * 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            a_off[u] = inside ? (unsigned)((((long)(gy - rowbase) * p.W + gx) * C + half * 8) * 2) : 0xffff0000u;     // (beyond any admissible extent -- the launcher keeps a window below 2^32 - 65536 bytes -- and the step's scalar offset cannot wrap it around)
         }
     };
-    plan_a(p.c0, in_plane0);
+    plan_a(p.c0);
     bool a_second = false;                  // the offsets are those of in1 (they depend on the channel count)
     constexpr int RSRC_FLAGS = 0x00020000;  // raw buffer, 32-bit data format (gfx9 resource word 3)
-    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.in0, 0, (int)(unsigned)(NPL * in_plane0 * 2), RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.in1, 0, (int)(unsigned)(NPL * in_plane1 * 2), RSRC_FLAGS);
+    // the window's start in every plane of in0 / in1 (scalars, no arrays: a private array of pointers would live in scratch); a copy
+    // instruction's plane follows from (u, wave), and its resource words are put together at the copy -- a few scalar moves
+    // the window's start in plane 0 of the CURRENT input, its plane stride and extent: scalars that switch once, when the chunks reach
+    // the second input (one copy path -- two branches with their own pointers made the compiler build a scratch table of them)
+    unsigned long long a_win = (unsigned long long)(p.in0 + (long)rowbase * p.W * p.c0), a_plane_bytes = (unsigned long long)in_plane0 * 2;
+    int a_rec = (int)(unsigned)((long)winrows * p.W * p.c0 * 2);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)0xffffffffu, RSRC_FLAGS);
     auto copy_a = [&](int chunk, int buf) {
         const int cbase = chunk * UC_KC;
         const bool second = cbase >= p.c0;
         if (second && !a_second) {          // (once per kernel, and only when a second input exists)
             a_second = true;
-            if (p.c1 != p.c0) plan_a(p.c1, in_plane1);
+            a_win = (unsigned long long)(p.in1 + (long)rowbase * p.W * p.c1);
+            a_plane_bytes = (unsigned long long)in_plane1 * 2;
+            a_rec = (int)(unsigned)((long)winrows * p.W * p.c1 * 2);
+            if (p.c1 != p.c0) plan_a(p.c1);
         }
         const int soff = (second ? cbase - p.c0 : cbase) * 2;
         lds_byte *dst = (lds_byte *)(sA + buf * A_BYTES + wave * 64 * 16);
-        if (second) {
 #pragma unroll
-            for (int u = 0; u < A_PER; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, dst + u * UC_THREADS * 16, 16, a_off[u], soff, 0, 0);
-        } else {
-#pragma unroll
-            for (int u = 0; u < A_PER; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, dst + u * UC_THREADS * 16, 16, a_off[u], soff, 0, 0);
+        for (int u = 0; u < A_PER; ++u) {
+            const int pl = min((u * (UC_THREADS / 64) + wave) / A_GPP, NPL - 1);      // this wave's plane (padding groups: every lane carries the out-of-range offset)
+            const unsigned long long base = a_win + (unsigned long long)pl * a_plane_bytes;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(a_rec), RSRC_FLAGS);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + u * UC_THREADS * 16, 16, a_off[u], soff, 0, 0);
         }
     };
     // weight slot q = u * THREADS + tid = (plane q / 256, n = (q % 256) / 2, stored half q & 1)
@@ -263,7 +330,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     int step = 0;
     int nc = D / p.ntaps, nt = D % p.ntaps;                  // (chunk, tap) of step + D
     int buf0 = 0, buf2 = D;                                  // weight buffers of steps s and s + D (no division in the loop)
-    bf16x8 fa[2][NPL], fb[4][NPL];
+    uint4 fa[2][NPL], fb[4][NPL];       // 16-byte fragments (eight pieces of either format)
 #ifdef UC_TRACE
     // clock sums over the main loop for ONE wave (block 0, wave 0): [0] copies issued, [1] fragment reads issued .. first operands
     // there (inside step_products), [2] products issued, [3] wait + barrier, [4] steps, [5] loop total
@@ -284,7 +351,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     // products from the smallest magnitude class to the largest; the same accumulator every 8 MFMAs
 #define UC_PRODUCT(PA, PB)                                                                                      \
     _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 4; ++n)                 \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][PB], fa[m][PA], acc[m][n], 0, 0, 0);
+        acc[m][n] = uc_mfma<F16>(fb[n][PB], fa[m][PA], acc[m][n]);
     auto step_products = [&](int chunk, int tap) {
         const unsigned char *abuf = sA + (chunk % (DA + 1)) * A_BYTES;
         const unsigned char *bbuf = sB + buf0 * B_BYTES;
@@ -295,24 +362,24 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
             const int px = (wave * 2 + m + 1 + dy) * UC_HW + (r + 1 + dx);
             aslot[m] = px * 2 + (h ^ ((px >> 3) & 1));
         }
-        auto read_a = [&](int m, int pl) { fa[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(abuf + (pl * UC_HP * 2 + aslot[m]) * 16)); };
-        auto read_b = [&](int n, int pl) { fb[n][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16)); };
+        auto read_a = [&](int m, int pl) { fa[m][pl] = *reinterpret_cast<const uint4 *>(abuf + (pl * A_PLANE + aslot[m]) * 16); };
+        auto read_b = [&](int n, int pl) { fb[n][pl] = *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16); };
         if constexpr (NPL == 2) {
             read_a(0, 1); read_a(1, 1);
 #pragma unroll
             for (int n = 0; n < 4; ++n) read_b(n, 0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);      // the wave whose operands are in registers goes first on the shared matrix pipe
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][0], fa[0][1], acc[0][0], 0, 0, 0);
+            acc[0][0] = uc_mfma<F16>(fb[0][0], fa[0][1], acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
             read_a(0, 0); read_a(1, 0);
 #pragma unroll
             for (int n = 0; n < 4; ++n) read_b(n, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 1; n < 4; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][0], fa[0][1], acc[0][n], 0, 0, 0);
+            for (int n = 1; n < 4; ++n) acc[0][n] = uc_mfma<F16>(fb[n][0], fa[0][1], acc[0][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][0], fa[1][1], acc[1][n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) acc[1][n] = uc_mfma<F16>(fb[n][0], fa[1][1], acc[1][n]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef UC_TWO_PRODUCTS        // (timing experiment of DESIGN 8: how the kernel's time follows the MFMA count; never part of the product)
             UC_PRODUCT(0, 1)
@@ -451,6 +518,12 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     {
         const float *bip = p.bias + nblk * UC_BN + 16 * hf;
         const float *scp = p.scale + nblk * UC_BN + 16 * hf, *shp = p.shift + nblk * UC_BN + 16 * hf;
+        const f32x2 inv2 = {p.acc_scale, p.acc_scale};      // fp16 pieces: accumulator -> the layer's units (a power of two)
+        // accumulator + bias (fp16 pieces: accumulator x acc_scale + bias, one fused multiply-add -- the product is exact)
+        auto biased = [&](float a0, float a1, const f32x2 &b) -> f32x2 {
+            if constexpr (F16) return __builtin_elementwise_fma(f32x2{a0, a1}, inv2, b);
+            else return f32x2{a0, a1} + b;
+        };
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -462,18 +535,26 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
                     const f32x2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        f32x2 v01 = f32x2{acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1]} + b01;
-                        f32x2 v23 = f32x2{acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3]} + b23;
+                        f32x2 v01 = biased(acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1], b01);
+                        f32x2 v23 = biased(acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3], b23);
                         v01 = __builtin_elementwise_fma(f32x2{relu_bits(v01[0]), relu_bits(v01[1])}, s01, t01);
                         v23 = __builtin_elementwise_fma(f32x2{relu_bits(v23[0]), relu_bits(v23[1])}, s23, t23);
+                        if constexpr (F16) {         // (stored values are scaled: s and t carry the activation scale)
+                            v01 = f32x2{uc_sat_f16(v01[0]), uc_sat_f16(v01[1])};
+                            v23 = f32x2{uc_sat_f16(v23[0]), uc_sat_f16(v23[1])};
+                        }
                         acc[m][n][q * 4 + 0] = v01[0]; acc[m][n][q * 4 + 1] = v01[1];
                         acc[m][n][q * 4 + 2] = v23[0]; acc[m][n][q * 4 + 3] = v23[1];
                     }
                 } else {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const f32x2 v01 = f32x2{acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1]} + b01;
-                        const f32x2 v23 = f32x2{acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3]} + b23;
+                        f32x2 v01 = biased(acc[m][n][q * 4 + 0], acc[m][n][q * 4 + 1], b01);     // (fp16 pieces, bias only: acc_scale and the bias carry the activation scale)
+                        f32x2 v23 = biased(acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3], b23);
+                        if constexpr (F16) {
+                            v01 = f32x2{uc_sat_f16(v01[0]), uc_sat_f16(v01[1])};
+                            v23 = f32x2{uc_sat_f16(v23[0]), uc_sat_f16(v23[1])};
+                        }
                         acc[m][n][q * 4 + 0] = v01[0]; acc[m][n][q * 4 + 1] = v01[1];
                         acc[m][n][q * 4 + 2] = v23[0]; acc[m][n][q * 4 + 3] = v23[1];
                     }
@@ -515,19 +596,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
         p.head_out[(long)p.H * p.W + o] = e1 / es;
         return;
     }
-    // rounds (a, b) to the next piece and keeps the remainders when more pieces follow; returns the packed word
-    auto piece_word = [](float &a, float &b, bool more) -> unsigned {
-        bf16x2 hv;
-        hv[0] = (__bf16)a;
-        hv[1] = (__bf16)b;
-        const unsigned w = __builtin_bit_cast(unsigned, hv);
-        if (more) {
-            const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
-            a = r[0];
-            b = r[1];
-        }
-        return w;
-    };
+    auto piece_word = [](float &a, float &b, bool more) -> unsigned { return uc_piece_word<F16>(a, b, more); };
     const int rd_row = lane >> 4, rd_col = (lane & 15) * 16;       // read-back: 16 lanes = one pixel's 256 bytes
     const long out_plane = (long)p.outH * p.outW * p.cout;
     if (p.pool_out) {
@@ -609,7 +678,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
 // a pixel's 256 bytes per piece leave in one piece.
 constexpr int FIRST_RUN = 32;       // consecutive pixels per 32-thread slot; a 256-thread block covers 8 runs = 256 pixels of a row
 constexpr int FIRST_PIX = 8 * FIRST_RUN;
-template <int NPL>
+template <int NPL, bool F16 = false>
 __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict__ in, int H, int W, const float *__restrict__ wgt /* [9][2][128] */,
                                                          const float *__restrict__ bias, const float *__restrict__ scale,
                                                          const float *__restrict__ shift, uint16_t *__restrict__ out)
@@ -668,21 +737,13 @@ __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict
             for (int j = 0; j < 4; ++j) {
                 const float r = a[j] > 0.f ? a[j] : 0.f;
                 a[j] = r * sv[j] + tv[j];
+                if constexpr (F16) a[j] = uc_sat_f16(a[j]);      // (s and t carry the activation scale)
             }
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
                 unsigned wd[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    bf16x2 hv;
-                    hv[0] = (__bf16)a[2 * q];
-                    hv[1] = (__bf16)a[2 * q + 1];
-                    wd[q] = __builtin_bit_cast(unsigned, hv);
-                    if (pl + 1 < NPL) {
-                        a[2 * q] -= __uint_as_float(wd[q] << 16);
-                        a[2 * q + 1] -= __uint_as_float(wd[q] & 0xffff0000u);
-                    }
-                }
+                for (int q = 0; q < 2; ++q) wd[q] = uc_piece_word<F16>(a[2 * q], a[2 * q + 1], pl + 1 < NPL);
                 *reinterpret_cast<uint2 *>(dst + (long)it * 128 + pl * plane) = make_uint2(wd[0], wd[1]);
             }
         }
@@ -690,20 +751,20 @@ __global__ void __launch_bounds__(256) k_unet_conv_first(const float *__restrict
 }
 
 // value of split element e (0..7) of the 16-byte pieces pc[0..NPL)
-template <int NPL>
+template <int NPL, bool F16 = false>
 __device__ __forceinline__ float split_value(const uint4 *pc, int e)
 {
     float v = 0.f;
 #pragma unroll
     for (int pl = NPL - 1; pl >= 0; --pl) {     // smallest piece first: the sum is exact either way (<= 24 significant bits)
         const unsigned w = e < 2 ? pc[pl].x : (e < 4 ? pc[pl].y : (e < 6 ? pc[pl].z : pc[pl].w));
-        v += bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
+        v += uc_piece_value<F16>((e & 1) ? (w >> 16) : (w & 0xffffu));
     }
     return v;
 }
 
 // ---- MaxPool2D(2) on split planes: the winner's pieces are copied (the pieces of a value are a function of the value) ---------
-template <int NPL>
+template <int NPL, bool F16 = false>
 __global__ void __launch_bounds__(256) k_unet_pool2(const uint16_t *__restrict__ in, int H, int W, int C, uint16_t *__restrict__ out)
 {
     const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
@@ -723,10 +784,10 @@ __global__ void __launch_bounds__(256) k_unet_pool2(const uint16_t *__restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         int best = 0;
-        float bv = split_value<NPL>(pc[0], e);
+        float bv = split_value<NPL, F16>(pc[0], e);
 #pragma unroll
         for (int k = 1; k < 4; ++k) {
-            const float v = split_value<NPL>(pc[k], e);
+            const float v = split_value<NPL, F16>(pc[k], e);
             if (v > bv) { bv = v; best = k; }
         }
 #pragma unroll
@@ -744,7 +805,7 @@ __global__ void __launch_bounds__(256) k_unet_pool2(const uint16_t *__restrict__
 
 // ---- head: Conv2D(128 -> 2, 1x1) + softmax over the two classes (pl.py:69), float32 out (2, H, W) -------------------------------
 // eight lanes per pixel, 16 channels each; logits != 0: the pre-softmax values (the bench's head calibration)
-template <int NPL>
+template <int NPL, bool F16 = false>
 __global__ void __launch_bounds__(256) k_unet_head(const uint16_t *__restrict__ in, long npix, const float *__restrict__ wgt /* [2][128] */,
                                                    const float *__restrict__ bias, float *__restrict__ out, int logits)
 {
@@ -761,7 +822,7 @@ __global__ void __launch_bounds__(256) k_unet_head(const uint16_t *__restrict__ 
             for (int pl = 0; pl < NPL; ++pl) pc[pl] = *reinterpret_cast<const uint4 *>(in + pl * plane + pix * 128 + part * 16 + g * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = split_value<NPL>(pc, e);
+                const float v = split_value<NPL, F16>(pc, e);
                 const int c = part * 16 + g * 8 + e;
                 z0 = __builtin_fmaf(v, wgt[c], z0);
                 z1 = __builtin_fmaf(v, wgt[128 + c], z1);

@@ -63,13 +63,24 @@ def shares_runtime_with_torch(t):
     return ok
 
 
+_MODES = {  # mode -> (pieces per value, piece format of the C-ABI: 0 bf16, 1 fp16, products per term, dropped part of a term)
+    "f16x3": (2, 1, 3, "7.2e-7"),
+    "bf16x3": (2, 0, 3, "1.6e-5"),
+    "bf16x6": (3, 0, 6, "9e-8"),
+}
+_F16_ACT_SCALE = 16.0      # fp16 pieces: activations are stored times 2^4 (saturate beyond |v| = 4094, absolute floor 2^-29)
+
+
 def _unet_mode():
-    """TISSUE_HIP_UNET_ARITH: 'bf16x3' (default: hand-written implicit-GEMM convolutions on the bf16 matrix cores, float32
-    operands split into two bf16 pieces, three products per term, float32 accumulation), 'bf16x6' (three pieces, six
-    products: float32-equivalent to 2^-23) or 'miopen' (PyTorch-ROCm / MIOpen float32 convolutions)."""
-    m = os.environ.get("TISSUE_HIP_UNET_ARITH", "bf16x3")
-    if m not in ("bf16x3", "bf16x6", "miopen"):
-        raise ValueError("TISSUE_HIP_UNET_ARITH must be bf16x3, bf16x6 or miopen")
+    """TISSUE_HIP_UNET_ARITH: how the hand-written implicit-GEMM convolutions feed the 16-bit matrix cores (float32 accumulation):
+    'f16x3' (default): float32 operands split into two fp16 pieces of power-of-two-scaled values, three products per term --
+        float32-equivalent (<= 3 x 2^-22 of a term is dropped) at three products;
+    'bf16x3': two bf16 pieces, three products per term (<= 2^-15.9 of a term dropped: 16 significand bits);
+    'bf16x6': three bf16 pieces, six products (float32-equivalent to 2^-23.4; twice the matrix work);
+    'miopen': PyTorch-ROCm / MIOpen float32 convolutions."""
+    m = os.environ.get("TISSUE_HIP_UNET_ARITH", "f16x3")
+    if m not in _MODES and m != "miopen":
+        raise ValueError("TISSUE_HIP_UNET_ARITH must be f16x3, bf16x3, bf16x6 or miopen")
     if os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32") != "fp32":
         m = "miopen"
     return m
@@ -83,11 +94,13 @@ def unet_arithmetic():
         if dt == "fp32":
             return {"dtype": "f32", "arithmetic": "float32 convolutions through PyTorch-ROCm / MIOpen (fp32 matrix pipe)", "peak_tflops": 157.3}
         return {"dtype": dt, "arithmetic": "%s convolutions through PyTorch-ROCm / MIOpen" % dt, "peak_tflops": 2500.0}
-    prods = 3 if m == "bf16x3" else 6
-    return {"dtype": "f32", "peak_tflops": 2500.0 / prods, "issued_flops_factor": prods, "issued_peak_tflops": 2500.0,
-            "arithmetic": "float32 operands split into %d bf16 pieces, %d bf16 MFMA products per term (relative error per term <= %s), "
-                          "float32 accumulation; hand-written implicit-GEMM kernels (csrc/tip_unet_conv.h); peak = dense bf16 MFMA "
-                          "peak / %d" % (2 if prods == 3 else 3, prods, "1.6e-5" if prods == 3 else "9e-8", prods)}
+    planes, fmt, prods, err = _MODES[m]
+    piece = "fp16" if fmt else "bf16"
+    return {"dtype": "f32(%s)" % m, "mode": m, "peak_tflops": 2500.0 / prods, "issued_flops_factor": prods, "issued_peak_tflops": 2500.0,
+            "float32_equivalent": m != "bf16x3",
+            "arithmetic": "float32 operands split into %d %s pieces, %d %s MFMA products per term (relative error per term <= %s), "
+                          "float32 accumulation; hand-written implicit-GEMM kernels (csrc/tip_unet_conv.h); peak = dense 16-bit MFMA "
+                          "peak / %d" % (planes, piece, prods, piece, err, prods)}
 
 
 def unet_algorithmic_bytes(h, w):
@@ -120,7 +133,8 @@ class _ConvDesc(ctypes.Structure):
                 ("dy", ctypes.c_int * 9), ("dx", ctypes.c_int * 9), ("cout", ctypes.c_int), ("bias", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_h", ctypes.c_int),
                 ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int),
-                ("pool_out", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("head_out", ctypes.c_void_p)]
+                ("pool_out", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("head_out", ctypes.c_void_p),
+                ("format", ctypes.c_int), ("acc_scale", ctypes.c_float)]
 
 
 _FILTERS = (128, 256, 512)
@@ -255,9 +269,37 @@ class _UNet(object):
         self.p["head.b"][0] += shift
         return shift
 
+    def randomize_statistics(self, seed=0):
+        """Synthetic-weights helper (tests / bench; no trained weights ship with the reference): gives every convolution a
+        non-zero bias and every BatchNormalization non-identity gamma / beta / moving mean / moving variance, drawn from a seeded
+        generator on the host (two instances with the same seed get the same values), so that the activations have the dynamic
+        range of a trained network instead of the half-zero, unit-scale maps of the he_normal / identity-BatchNorm initialisation."""
+        torch = self.torch
+        g = torch.Generator().manual_seed(1000 + seed)
+        for k in sorted(self.p):
+            v = self.p[k]
+            if k.endswith(".b") and k != "head.b":
+                new = torch.randn(v.numel(), generator=g) * 0.1
+            elif k.endswith(".s"):                 # gamma / sqrt(var + eps): gamma in [0.5, 1.5], var in [0.5, 1.5]
+                c = v.numel()
+                gamma, var = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) + 0.5
+                beta, mean = torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.2
+                scale = gamma.double() / torch.sqrt(var.double() + _BN_EPS)
+                self.p[k] = scale.to(device=v.device, dtype=v.dtype).view(v.shape)
+                t = k[:-2] + ".t"
+                self.p[t] = (beta.double() - mean.double() * scale).to(device=v.device, dtype=v.dtype).view(self.p[t].shape)
+                continue
+            else:
+                continue
+            self.p[k] = new.to(device=v.device, dtype=v.dtype).view(v.shape)
+        for m in list(_MODES):
+            if hasattr(self, "_hipw_" + m):
+                delattr(self, "_hipw_" + m)
+
     # -- hand-written convolution path (csrc/tip_unet_conv.h) ---------------------------------------------------------------
-    def _split_pack(self, taps, planes):
-        """taps: (T, Cin, Cout) float32 on the device -> packed split weights [T][Cin/16][Cout/128][plane][128][16] bf16.
+    def _split_pack(self, taps, planes, fmt=0):
+        """taps: (T, Cin, Cout) float32 on the device -> packed split weights [T][Cin/16][Cout/128][plane][128][16] in bf16 (fmt 0) or
+        fp16 (fmt 1: the caller has scaled the taps into fp16's range) pieces.
 
         Row order inside every group of 32 output channels: row 8 g + 4 h + j (g < 4, h < 2, j < 4) holds channel 16 h + 4 g + j --
         the matrix core's output register i = 4 g + j of half-wave h is then channel 16 h + i, i.e. a lane of the kernel ends up with
@@ -266,7 +308,7 @@ class _UNet(object):
         T, cin, cout = taps.shape
         pieces, rest = [], taps.float()
         for _ in range(planes):
-            h = rest.to(torch.bfloat16)
+            h = rest.to(torch.float16 if fmt else torch.bfloat16)
             pieces.append(h)
             rest = rest - h.float()
         row = torch.arange(32, device=taps.device)
@@ -275,18 +317,34 @@ class _UNet(object):
         pk = pk.reshape(planes, T, cin // 16, 16, cout // 128, 128)
         return pk.permute(1, 2, 4, 0, 5, 3).contiguous()
 
-    def _hip_weights(self, planes):
-        key = "_hipw%d" % planes
+    def _hip_weights(self, mode):
+        """Packed weights and per-channel constants of one arithmetic mode.  fp16 pieces (mode f16x3) carry power-of-two scales:
+        activations are stored times A = 2^4, a layer's weights times W = the power of two that puts its largest weight in
+        [2^14, 2^15); the kernel multiplies the accumulator by 1 / (A W) before the bias (entry 3 of a layer's tuple), the
+        BatchNorm scale / shift (and a bias-only layer's bias and accumulator factor) are multiplied by A, the head's weights by
+        1 / A -- exact, so the stored values are A times what the unscaled network computes, bit for bit."""
+        key = "_hipw_" + mode
         if getattr(self, key, None) is not None:
             return getattr(self, key)
         torch = self.torch
         p = self.p
+        planes, fmt = _MODES[mode][:2]
+        act = _F16_ACT_SCALE if fmt else 1.0
         hw = {}
+
+        def pack(taps, bias_only):
+            if not fmt:
+                return self._split_pack(taps, planes), 1.0
+            big = float(taps.abs().max())
+            wscale = 2.0 ** (14 - int(np.floor(np.log2(big)))) if big > 0 and np.isfinite(big) else 1.0
+            inv = 1.0 / (act * wscale)
+            return self._split_pack(taps * wscale, planes, fmt), (inv * act if bias_only else inv)
 
         def conv3(name):
             w = p[name + ".w"].float()                                  # (cout, cin, 3, 3): cross-correlation, tap (ky, kx) reads (y + ky - 1, x + kx - 1)
             taps = torch.stack([w[:, :, ky, kx].t() for ky in range(3) for kx in range(3)], 0)
-            hw[name] = (self._split_pack(taps, planes), [ky - 1 for ky in range(3) for kx in range(3)], [kx - 1 for ky in range(3) for kx in range(3)])
+            wp, inv = pack(taps, False)
+            hw[name] = (wp, [ky - 1 for ky in range(3) for kx in range(3)], [kx - 1 for ky in range(3) for kx in range(3)], inv)
 
         def conv_t(name):
             # conv_transpose2d(stride 2): out[2 i + k] += in[i] w[k], cropped to the first 2N rows / columns.  Even outputs take
@@ -297,7 +355,8 @@ class _UNet(object):
                 for px in (0, 1):
                     tl = [(ky, dy, kx, dx) for ky, dy in per_axis[py] for kx, dx in per_axis[px]]
                     taps = torch.stack([w[:, :, ky, kx] for ky, _, kx, _ in tl], 0)
-                    hw["%s.%d%d" % (name, py, px)] = (self._split_pack(taps, planes), [t[1] for t in tl], [t[3] for t in tl])
+                    wp, inv = pack(taps, True)
+                    hw["%s.%d%d" % (name, py, px)] = (wp, [t[1] for t in tl], [t[3] for t in tl], inv)
 
         for blk in ("d0", "d1", "d2", "mid", "u0", "u1", "u2"):
             if blk != "d0":
@@ -307,28 +366,30 @@ class _UNet(object):
             conv_t("u%d.t" % i)
         w0 = p["d0.c1.w"].float()                                       # (128, 2, 3, 3) -> [tap][ci][cout]
         hw["first"] = w0.permute(2, 3, 1, 0).reshape(18, 128).contiguous()
-        hw["head"] = p["head.w"].float().reshape(2, 128).contiguous()
+        hw["head"] = (p["head.w"].float().reshape(2, 128) / act).contiguous()
         for k in list(p):
             if k.endswith((".b", ".s", ".t")) and not k.endswith(".t.w"):
-                hw["f:" + k] = p[k].float().reshape(-1).contiguous()
+                v = p[k].float().reshape(-1)
+                # times A: BatchNorm scale (".s") / shift (".t"), and the bias of a bias-only (transposed convolution) layer (".t.b")
+                scaled = k.endswith((".s", ".t", ".t.b"))
+                hw["f:" + k] = (v * act if scaled else v).contiguous()
         setattr(self, key, hw)
         return hw
 
     def hip_path_ok(self, x):
-        """The hand-written kernels tile every level's grid in 8 x 32 pixels: extents that are multiples of 64 x 256, and an
-        activation tensor has to stay below 4 GB."""
+        """The hand-written kernels tile every level's grid in 8 x 32 pixels: extents that are multiples of 64 x 256 (what
+        prepare_image's padding to powers of two yields for every frame of at least 33 x 129 pixels).  No size limit: a tile
+        addresses its halo window, not the tensor."""
         torch = self.torch
-        planes = 2 if _unet_mode() == "bf16x3" else 3
-        # (the kernels address a layer's input through 32-bit buffer offsets: planes x H x W x 128 channels x 2 bytes < 4 GB,
-        #  i.e. frames up to 2048 x 4095 with two pieces; larger ones take the MIOpen route)
         return (_unet_mode() != "miopen" and x.is_cuda and self.dtype == torch.float32 and x.shape[0] == 1 and x.shape[1] == 2
-                and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and planes * x.shape[2] * x.shape[3] * 256 < (1 << 32) - 65536
-                and shares_runtime_with_torch(x))
+                and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and shares_runtime_with_torch(x))
 
     def _forward_hip(self, x, logits):
         torch = self.torch
-        planes = 2 if _unet_mode() == "bf16x3" else 3
-        hw = self._hip_weights(planes)
+        mode = _unet_mode()
+        planes, fmt = _MODES[mode][:2]
+        hw = self._hip_weights(mode)
+        self.last_mode = mode                 # (bench.py / tests: which arithmetic the last forward pass really used)
         lib = _lib.lib()
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         H, W = int(x.shape[2]), int(x.shape[3])
@@ -348,12 +409,13 @@ class _UNet(object):
             return r
 
         def buf(h, w, c):
-            return torch.empty((planes, h, w, c), dtype=torch.bfloat16, device=x.device)
+            return torch.empty((planes, h, w, c), dtype=torch.float16 if fmt else torch.bfloat16, device=x.device)
 
         def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None):
-            wp, dy, dx = hw[name]
+            wp, dy, dx, inv = hw[name]
             cout = wp.shape[2] * 128
             d = _ConvDesc()
+            d.format, d.acc_scale = fmt, inv
             d.in0, d.c0 = src.data_ptr(), src.shape[3]
             d.in1, d.c1 = (skip.data_ptr(), skip.shape[3]) if skip is not None else (None, 0)
             d.h, d.w, d.planes = h, w, planes
@@ -381,7 +443,7 @@ class _UNet(object):
                 a = buf(h, w, 128)
                 timed("first %dx%d 2->128" % (h, w), 2.0 * h * w * 18 * 128,
                       lambda: _lib.check(lib.tip_unet_conv_first_dev(D(x), h, w, D(hw["first"]), D(hw["f:d0.c1.b"]), D(hw["f:d0.b1.s"]),
-                                                                     D(hw["f:d0.b1.t"]), D(a), planes, stream)))
+                                                                     D(hw["f:d0.b1.t"]), D(a), planes, fmt, stream)))
             else:
                 a = conv(blk + ".c1", src, skip, h, w, blk + ".b1")
             return conv(blk + ".c2", a, None, h, w, blk + ".b2", pooled=pooled, head=head)
@@ -389,7 +451,7 @@ class _UNet(object):
         def pool(t, h, w):
             o = buf(h // 2, w // 2, t.shape[3])
             timed("pool %dx%d x%d" % (h, w, t.shape[3]), 0.0,
-                  lambda: _lib.check(lib.tip_unet_pool2_dev(D(t), h, w, int(t.shape[3]), planes, D(o), stream)))
+                  lambda: _lib.check(lib.tip_unet_pool2_dev(D(t), h, w, int(t.shape[3]), planes, fmt, D(o), stream)))
             return o
 
         with torch.no_grad():
@@ -419,7 +481,7 @@ class _UNet(object):
                 cur = double("u%d" % i, up, skips[2 - i], h, w)
             out = torch.empty((1, 2, H, W), dtype=torch.float32, device=x.device)
             timed("head %dx%d" % (H, W), 2.0 * H * W * 256,
-                  lambda: _lib.check(lib.tip_unet_head_dev(D(cur), ctypes.c_long(H * W), D(hw["head"]), D(hw["f:head.b"]), D(out), planes,
+                  lambda: _lib.check(lib.tip_unet_head_dev(D(cur), ctypes.c_long(H * W), D(hw["head"]), D(hw["f:head.b"]), D(out), planes, fmt,
                                                            1 if logits else 0, stream)))
         return out
 
@@ -429,6 +491,7 @@ class _UNet(object):
         F = torch.nn.functional
         if self.hip_path_ok(x):
             return self._forward_hip(x, logits)
+        self.last_mode = "miopen"
         with torch.no_grad():
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             skips = []
