@@ -30,6 +30,27 @@ def test_network_gpu_vs_cpu_float64():
     assert float((out - exp).abs().max()) < 1e-4
 
 
+def test_predictor_loads_a_keras_h5_checkpoint():
+    """SegmentationPredictor(UNET_WEIGHTS_PATH, shape) as gui.py:2062 calls it, with a Keras-layout `.h5` (fixture written by
+    the real HDF5 library, reduced widths): the weights arrive in build_unet_model's order -- the device network equals the
+    float64 host network built from the same file -- and predict() runs end to end."""
+    import os
+    import torch
+    from tissue_image_processing_amd import prediction_local as pl
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_tiny_unet_weights.h5")
+    rng = np.random.default_rng(2)
+    img = rng.random((2, 100, 70)) * 1000
+    pred = pl.SegmentationPredictor(path, img.shape)
+    assert pred.model.filters == (4, 8, 16) and pred.model.bottleneck == 32
+    ref = pl._UNet(2, "cpu", dtype=torch.float64, weights=pl.load_keras_weight_list(path))
+    padded, _ = pred.prepare_image(img)
+    out = pred.model.forward(padded).cpu().double()
+    exp = ref.forward(padded.cpu().double())
+    assert float((out - exp).abs().max()) < 1e-4
+    labels, hc = pred.predict(img)
+    assert labels.shape == (70, 100) and labels.dtype == np.int32 and hc.shape == (70, 100)
+
+
 def test_predict_shapes_and_padding():
     from tissue_image_processing_amd import prediction_local as pl, synthetic
     rng = np.random.default_rng(1)

@@ -11,9 +11,9 @@ Deliberate deviations from the reference (documented in DESIGN.md):
   * pl.py:96-135 writes nine debug TIFFs to hard-coded C:\\Users\\... paths on every call; not reproduced.
   * the 101-fold closing loop (pl.py:170-174) is applied once: grey closing with a flat footprint is idempotent
     (pinned by tests/golden/rank_filters.npz closed_101 == closed_once).
-  * Keras .h5 checkpoints cannot be read here (no TensorFlow / h5py in the image): weights are read from an .npz
-    holding model.get_weights() in layer order, or random-initialised when the path is None.
-    No weights ship with the reference (gui.py:38-39 points at a local .h5), so network parity is unpinned.
+  * Keras .h5 checkpoints (gui.py:38-39, pl.py:76-88) are read by a self-contained HDF5 reader (_hdf5.py: no h5py /
+    TensorFlow in the image); an .npz holding model.get_weights() in layer order is accepted too, and a path of None
+    gives random initialisation.  No weights ship with the reference, so the TRAINED network's parity is unpinned.
 """
 import ctypes
 import os
@@ -168,19 +168,34 @@ class _UNet(object):
     concatenate([upsampled, skip]); Conv2D(2, 1) + softmax over channels.
     """
 
-    def __init__(self, in_ch=2, device="cuda", dtype=None, weights=None, seed=0):
+    def __init__(self, in_ch=2, device="cuda", dtype=None, weights=None, seed=0, filters=None, bottleneck=None):
         import torch
         self.torch = torch
         self.device = device
+        if weights is not None:                   # the widths are the checkpoint's (12 arrays per double block: 2 x (kernel, bias, 4 BN vectors))
+            weights = list(weights)
+            if len(weights) != 12 * 7 + 2 * 3 + 2:
+                raise ValueError("the U-Net of pl.py:31-72 has 92 weight arrays, the checkpoint holds %d" % len(weights))
+            filters = tuple(int(weights[12 * i].shape[3]) for i in range(3))
+            bottleneck = int(weights[36].shape[3])
+        self.filters = tuple(filters) if filters is not None else _FILTERS
+        self.bottleneck = int(bottleneck) if bottleneck is not None else 1024
         self.dtype = dtype or {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[
             os.environ.get("TISSUE_HIP_UNET_DTYPE", "fp32")]
         g = torch.Generator().manual_seed(seed)
         self.p = {}
         it = iter(weights) if weights is not None else None
 
+        def expect(name, arr, shape):
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError("checkpoint does not fit the U-Net of pl.py:31-72: %s has shape %s, expected %s"
+                                 % (name, tuple(arr.shape), tuple(shape)))
+            return np.ascontiguousarray(arr, dtype=np.float32)
+
         def conv(name, cin, cout, k):
             if it is not None:
                 kern, bias = next(it), next(it)  # Keras (kh, kw, in, out)
+                kern, bias = expect(name + " kernel", kern, (k, k, cin, cout)), expect(name + " bias", bias, (cout,))
                 w = torch.from_numpy(np.ascontiguousarray(kern)).permute(3, 2, 0, 1)
                 b = torch.from_numpy(np.ascontiguousarray(bias))
             else:
@@ -192,7 +207,7 @@ class _UNet(object):
 
         def bn(name, c):
             if it is not None:
-                gamma, beta, mean, var = (torch.from_numpy(np.ascontiguousarray(next(it))) for _ in range(4))
+                gamma, beta, mean, var = (torch.from_numpy(expect(name + " statistics", next(it), (c,))) for _ in range(4))
             else:
                 gamma, beta, mean, var = torch.ones(c), torch.zeros(c), torch.zeros(c), torch.ones(c)
             scale = gamma.double() / torch.sqrt(var.double() + _BN_EPS)
@@ -203,6 +218,7 @@ class _UNet(object):
         def convT(name, cin, cout):
             if it is not None:
                 kern, bias = next(it), next(it)  # Keras Conv2DTranspose kernel (kh, kw, out, in)
+                kern, bias = expect(name + " kernel", kern, (3, 3, cout, cin)), expect(name + " bias", bias, (cout,))
                 w = torch.from_numpy(np.ascontiguousarray(kern)).permute(3, 2, 0, 1)  # torch: (in, out, kh, kw)
                 b = torch.from_numpy(np.ascontiguousarray(bias))
             else:
@@ -219,12 +235,12 @@ class _UNet(object):
             bn(name + ".b2", cout)
 
         c = in_ch
-        for i, f in enumerate(_FILTERS):
+        for i, f in enumerate(self.filters):
             double("d%d" % i, c, f)
             c = f
-        double("mid", c, 1024)
-        c = 1024
-        for i, f in enumerate(reversed(_FILTERS)):
+        double("mid", c, self.bottleneck)
+        c = self.bottleneck
+        for i, f in enumerate(reversed(self.filters)):
             convT("u%d.t" % i, c, f)
             double("u%d" % i, 2 * f, f)
             c = f
@@ -382,6 +398,7 @@ class _UNet(object):
         addresses its halo window, not the tensor."""
         torch = self.torch
         return (_unet_mode() != "miopen" and x.is_cuda and self.dtype == torch.float32 and x.shape[0] == 1 and x.shape[1] == 2
+                and self.filters == _FILTERS and self.bottleneck == 1024        # (the reference's widths, pl.py:60-69)
                 and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and shares_runtime_with_torch(x))
 
     def _forward_hip(self, x, logits):
@@ -514,12 +531,12 @@ class _UNet(object):
         """Dense multiply-add count x2 of one forward pass (for the MFMA roofline)."""
         total = 0
         c, hh, ww = 2, h, w
-        for f in _FILTERS:
+        for f in self.filters:
             total += 2 * hh * ww * 9 * (c * f + f * f)
             c, hh, ww = f, hh // 2, ww // 2
-        total += 2 * hh * ww * 9 * (c * 1024 + 1024 * 1024)
-        c = 1024
-        for f in reversed(_FILTERS):
+        total += 2 * hh * ww * 9 * (c * self.bottleneck + self.bottleneck * self.bottleneck)
+        c = self.bottleneck
+        for f in reversed(self.filters):
             hh, ww = hh * 2, ww * 2
             total += 2 * (hh // 2) * (ww // 2) * 9 * c * f            # transpose conv
             total += 2 * hh * ww * 9 * (2 * f * f + f * f)
@@ -529,16 +546,50 @@ class _UNet(object):
 
 
 def load_keras_weight_list(path):
-    """Weights as the ordered list model.get_weights() returns (np.savez(path, *model.get_weights()))."""
+    """The checkpoint's arrays in model.get_weights() order (layer order of build_unet_model, pl.py:31-72; per layer Conv2D:
+    kernel, bias; BatchNormalization: gamma, beta, moving_mean, moving_variance; Conv2DTranspose: kernel, bias).
+
+    `.h5` / `.hdf5` / `.keras`-named HDF5 files -- what model.save_weights() / model.save() write and what pl.py:86
+    (`model.load_weights(self.weights_path)`) reads -- go through the self-contained reader of _hdf5.py: like Keras' loading
+    by topology, the file's layers that carry weights are taken in file order; the layer kinds are checked against the
+    network's (a checkpoint of another architecture raises ValueError, as Keras does).  `.npz`: np.savez(path, *model.get_weights())."""
     if path is None:
         return None
     if not os.path.exists(path):
         raise OSError("Unable to open file (unable to open file: name = '%s')" % path)  # h5py/Keras wording
-    if path.endswith(".npz"):
+    if str(path).endswith(".npz"):
         z = np.load(path)
         return [z["arr_%d" % i] for i in range(len(z.files))]
-    raise OSError("Keras .h5 checkpoints cannot be read in this environment (no h5py/TensorFlow); export with "
-                  "np.savez(path, *model.get_weights()) -- see INTEGRATION.md")
+    from . import _hdf5
+    layers = [(name, ws) for name, ws in _hdf5.load_keras_weights_h5(path) if ws]
+    # build_unet_model's weight-carrying layers: 7 double blocks of (Conv2D, BN, Conv2D, BN), a Conv2DTranspose in front of each
+    # of the last three, the 1x1 Conv2D head
+    kinds = ["conv", "bn", "conv", "bn"] * 4
+    for _ in range(3):
+        kinds += ["convT", "conv", "bn", "conv", "bn"]
+    kinds += ["conv"]
+    if len(layers) != len(kinds):
+        raise ValueError("You are trying to load a weight file containing %d layers into a model with %d layers." % (len(layers), len(kinds)))
+    out = []
+    for (name, ws), kind in zip(layers, kinds):
+        arrs = [a for _, a in ws]
+        ok = {"conv": len(arrs) == 2 and arrs[0].ndim == 4 and arrs[1].ndim == 1,
+              "convT": len(arrs) == 2 and arrs[0].ndim == 4 and arrs[1].ndim == 1 and arrs[0].shape[2] == arrs[1].shape[0],
+              "bn": len(arrs) == 4 and all(a.ndim == 1 for a in arrs)}[kind]
+        if kind == "conv" and ok:
+            ok = arrs[0].shape[3] == arrs[1].shape[0]
+        if not ok:
+            raise ValueError("checkpoint layer '%s' (%s) does not fit the %s layer of the U-Net of pl.py:31-72 at that position"
+                             % (name, ", ".join(str(a.shape) for a in arrs), {"conv": "Conv2D", "convT": "Conv2DTranspose", "bn": "BatchNormalization"}[kind]))
+        if kind == "bn":                          # by name where Keras names them (gamma / beta may be absent from odd configurations)
+            order = {"gamma": 0, "beta": 1, "moving_mean": 2, "moving_variance": 3}
+            keyed = sorted(ws, key=lambda t: order.get(t[0].split("/")[-1].split(":")[0], 99))
+            if all(t[0].split("/")[-1].split(":")[0] in order for t in ws):
+                arrs = [a for _, a in keyed]
+        elif all(t[0].split("/")[-1].split(":")[0] in ("kernel", "bias") for t in ws):
+            arrs = [a for _, a in sorted(ws, key=lambda t: 0 if t[0].split("/")[-1].startswith("kernel") else 1)]
+        out.extend(arrs)
+    return out
 
 
 class SegmentationPredictor:
