@@ -92,11 +92,13 @@ def algorithmic_dp_ops(kernel, Z, Y, X):
     return None
 
 
-def cpu_baseline_worker(Ys, Xs, Z, workload, threads):
+def cpu_baseline_worker(Ys, Xs, Z, workload, threads, seg=0):
     """One CPU-baseline sample: the C/numpy oracle (a port of the reference path, single thread like scipy.ndimage /
-    skimage) on a crop of the workload.  For the U-Net workload the network itself is the SAME float32 network run by
-    torch on the host cores (`threads` of them) on a 512^2 crop -- TensorFlow-CPU's role in the reference -- and the tail is
-    the oracle's restatement of pl.py:167-194 (101 closings, as upstream).  Prints the seconds of every stage."""
+    skimage).  The projection runs on a Ys x Xs frame (the single-process record: the WHOLE frame), the segmentation stages on
+    its top-left seg x seg corner (0: all of it), reported as measured -- the caller scales by pixel count and says so.  For the
+    U-Net workload the network itself is the SAME float32 network run by torch on the host cores (`threads` of them) on a 512^2
+    crop -- TensorFlow-CPU's role in the reference -- and the tail is the oracle's restatement of pl.py:167-194 (101 closings,
+    as upstream).  Prints the seconds of every stage."""
     from oracle import oracle as orc
     from tissue_image_processing_amd import synthetic
     st = synthetic.make_stack(Z, Ys, Xs, seed=1234)
@@ -105,11 +107,13 @@ def cpu_baseline_worker(Ys, Xs, Z, workload, threads):
     t_proj = time.perf_counter() - t0
     t_seg = t_fwd = 0.0
     fwd_px = 0
+    sy, sx = (min(seg, Ys), min(seg, Xs)) if seg else (Ys, Xs)
     if workload == "classical":
+        crop = np.ascontiguousarray(proj[0][:sy, :sx])
         t1 = time.perf_counter()
-        lab = orc.watershed_segmentation(proj[0], 0.03, 3, 3)
+        lab = orc.watershed_segmentation(crop, 0.03, 3, 3)
         orc.frame_cellinfo(lab)
-        t_seg = time.perf_counter() - t1
+        t_seg = (time.perf_counter() - t1) * (Ys * Xs) / float(sy * sx)    # scaled to the projection's frame
     elif workload == "unet":
         import torch
         from tissue_image_processing_amd.prediction_local import _UNet
@@ -130,14 +134,14 @@ def cpu_baseline_worker(Ys, Xs, Z, workload, threads):
     print("CPU_BASELINE_SECONDS %.6f %.6f %.6f %d" % (t_proj, t_seg, t_fwd, fwd_px))
 
 
-def cpu_baseline(sample_yx, Z, workload, nproc, threads=1):
+def cpu_baseline(sample_yx, Z, workload, nproc, threads=1, seg=0):
     """Runs the sample in `nproc` child processes at once (started BEFORE this process touches the GPU) and returns the
     list of per-process (projection s, segmentation s, network s, network pixels): nproc = 1 is the single-process figure,
     nproc = host cores the embarrassingly parallel "N frames on N processes" one (scipy.ndimage / skimage are
     single-threaded)."""
     import subprocess
     Ys, Xs = sample_yx
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload, str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload, str(threads), str(seg)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS=str(threads))
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(nproc)]
     secs = []
@@ -151,9 +155,10 @@ def cpu_baseline(sample_yx, Z, workload, nproc, threads=1):
 
 
 def cpu_baseline_record(Y, X, Z, workload):
-    """cpu_baseline object of the JSON line for `workload` (classical / projection / unet)."""
-    Ys, Xs = min(Y, 1408), min(X, 1408)
-    scale = (Y * X) / float(Ys * Xs)
+    """cpu_baseline object of the JSON line for `workload` (classical / projection / unet): the projection on ONE WHOLE frame
+    (~16 s on one core at 2048^2 x 30), the segmentation + tables on its 1024^2 corner and (U-Net workload) the network on a
+    512^2 crop, both scaled by pixel count -- a bounded sample, stated in `sample`."""
+    SEG = 1024
     host_cores = os.cpu_count() or 1
     try:
         host_cores = len(os.sched_getaffinity(0))
@@ -161,27 +166,31 @@ def cpu_baseline_record(Y, X, Z, workload):
         pass
     threads = max(1, min(host_cores, 32)) if workload == "unet" else 1
 
-    def frame_seconds(rec):
+    def frame_seconds(rec, scale):
         t_proj, t_seg, t_fwd, fwd_px = rec
         return (t_proj + t_seg) * scale + (t_fwd * (Y * X) / float(fwd_px) if fwd_px else 0.0)
 
-    one = cpu_baseline((Ys, Xs), Z, workload, 1, threads)[0]
-    sec = frame_seconds(one)
+    one = cpu_baseline((Y, X), Z, workload, 1, threads, seg=SEG)[0]
+    sec = frame_seconds(one, 1.0)
+    seg_scale = (Y * X) / float(min(SEG, Y) * min(SEG, X))
     rec = {"value": 1.0 / sec, "unit": "frames/s", "cores": threads, "kind": "port", "host_cores": host_cores, "workload": workload,
-           "sample": "%dx%dx%d crop (1/%g of a frame) through the C/numpy oracle (%s path): projection %.1f s, segmentation + "
-                     "tables %.1f s on one core, scaled by pixel count" % (Ys, Xs, Z, scale, workload, one[0], one[1])}
+           "sample": "one whole %dx%dx%d frame through the C/numpy oracle's projection (%.1f s on one core, unscaled); segmentation + "
+                     "tables of the %s path on its %dx%d corner, scaled x%g by pixel count to %.1f s" % (Y, X, Z, one[0], workload, min(SEG, Y), min(SEG, X), seg_scale, one[1])}
     if workload == "unet":
         rec["sample"] += ("; network = the same float32 U-Net through torch-CPU on %d threads, 512^2 crop %.1f s scaled x%g "
                           "(%.2f TFLOP/s)" % (threads, one[2], (Y * X) / float(one[3]),
                                               19.8 * one[3] / (2048.0 * 2048.0) / max(one[2], 1e-9)))
-        rec["stages_s_per_frame"] = {"projection": one[0] * scale, "tail_and_tables": one[1] * scale,
+        rec["stages_s_per_frame"] = {"projection": one[0], "tail_and_tables": one[1],
                                      "network": one[2] * (Y * X) / float(one[3])}
     else:
+        Ys, Xs = min(Y, 1024), min(X, 1024)
+        scale = (Y * X) / float(Ys * Xs)
         nproc = max(1, min(host_cores, 16))
-        many = cpu_baseline((Ys, Xs), Z, workload, nproc) if nproc > 1 else [one]
-        slowest = max(frame_seconds(m) for m in many)
+        many = cpu_baseline((Ys, Xs), Z, workload, nproc)
+        slowest = max(frame_seconds(m, scale) for m in many)
         rec["n_process"] = {"processes": nproc, "value": nproc / slowest, "unit": "frames/s",
-                            "sample": "the same crop in %d processes at once (one frame each), slowest %.1f s per frame" % (nproc, slowest)}
+                            "sample": "a %dx%dx%d crop (1/%g of a frame) in %d processes at once, scaled by pixel count: slowest %.1f s per frame"
+                                      % (Ys, Xs, Z, scale, nproc, slowest)}
     return rec
 
 
@@ -208,10 +217,22 @@ def launch_ranks(args, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all of them: when one rank dies (device missing, import error) the others would sit in init_process_group / a barrier
+    # until the collective timeout -- they are terminated and the failing rank's code is returned
     worst = 0
-    for p in procs:
-        rc = p.wait()
-        worst = worst or rc
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
     return worst
 
 
@@ -222,7 +243,8 @@ def stub_rank(args, rank, world):
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=2))
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -276,6 +298,7 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    backend.close()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,7 +322,8 @@ def bench_movie(args, rank, local_rank, world, dist, torch):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
-        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]))
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]),
+                                   int(sys.argv[7]) if len(sys.argv) > 7 else 0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
@@ -365,7 +389,9 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(minutes=5))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -379,6 +405,7 @@ def main():
     if workload == "movie":
         return bench_movie(args, rank, local_rank, world, dist, torch)
     lib = _lib.lib()
+    from tissue_image_processing_amd import prediction_local as plm
 
     # synthetic frames, resident in HBM before the timed region (two distinct frames per rank, alternated)
     import threading
@@ -487,6 +514,8 @@ def main():
                 lab_ptr = pipe.d_labels.ptr
             elif self.workload == "unet":
                 lab, _ = pipe.segment_unet(self.predictor)
+                if getattr(self.predictor.model, "last_mode", None) != unet_mode:       # a silent fall-back to MIOpen must not be timed under this label
+                    raise RuntimeError("the U-Net step ran in mode %r, the bench line says %r" % (getattr(self.predictor.model, "last_mode", None), unet_mode))
                 self.diag.append((int(self.predictor.last_flags), int(self.predictor.last_markers)))
                 pipe.cell_tables(labels_ptr=lab.data_ptr(), shape=(X, Y))
                 lab_ptr = lab.data_ptr()
@@ -653,13 +682,15 @@ def main():
                 out_k[k]["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
         return out_k
 
+    class _FlopsShape(object):          # (flops() only needs the widths)
+        filters, bottleneck = plm._FILTERS, 1024
+
     def unet_roofline(leg):
         """MFMA roofline of the U-Net forward pass, the dominant kernel group of config 3: dense conv flops of pl.py:31-72 at
         the padded size / the forward pass's duration (events on the stream the network is launched on, around the network
         only, one frame in flight)."""
-        from tissue_image_processing_amd import prediction_local as plm
         hp, wp = plm.find_desired_shape(X, Y)
-        flops = plm._UNet.flops(None, hp, wp)
+        flops = plm._UNet.flops(_FlopsShape(), hp, wp)
         ms = leg["iso_unet_ms"] or leg["unet_ms"]
         fwd_ms = float(np.median(ms)) if ms else None
         info = plm.unet_arithmetic()
@@ -672,6 +703,8 @@ def main():
         tr_paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_unet_pmc_traffic.json")))
         if tr_paths and (hp, wp) == (2048, 2048) and info.get("issued_flops_factor", 1) == 3:
             recs = json.load(open(tr_paths[-1]))
+            r["traffic_note"] = ("rocprofv3 --pmc counters of a separate, committed run of this network (profiles/%s), not of this run: "
+                                 "a cross-reference" % os.path.basename(tr_paths[-1]))
             tot = sum((v["fetch_MB_per_call_x2corrected"] + v["write_MB_per_call"]) * v["calls"] for k, v in recs.items() if k.startswith("k_unet_"))
             # forward passes in that counter run: the first layer is launched once per pass (the head is fused into the last convolution)
             per_pass = [v["calls"] for k, v in recs.items() if k.startswith("k_unet_conv_first")] or [v["calls"] for k, v in recs.items() if k.startswith("k_unet_head")]
@@ -686,12 +719,45 @@ def main():
             if info.get("issued_flops_factor", 1) != 1:
                 r["issued_tflops"] = r["achieved"] * info["issued_flops_factor"]
                 r["issued_frac_of_bf16_peak"] = r["issued_tflops"] / info["issued_peak_tflops"]
-                r["note"] = ("`peak` is the nominal dense bf16 peak / 3 products; back-to-back v_mfma_f32_32x32x16_bf16 from registers with "
-                             "random operand bits sustain 1.78-1.97 PFLOP/s (71-79 % of 2.5) at a power-limited 1.77-1.93 GHz on this chip "
-                             "(tools/ubench/mfma_bf16_rate.hip, profiles/r03d_mfma_bf16_rate.txt)")
+                r["note"] = ("`peak` is the nominal dense 16-bit MFMA peak / the products per term; back-to-back 32x32x16 MFMAs from registers "
+                             "with random operand bits sustain 1.70-1.75 PFLOP/s in fp16 and 1.85-1.94 in bf16 (68-78 % of 2.5) at a "
+                             "power-limited 1.7-1.9 GHz on this chip (tools/ubench/mfma_f16_rate.hip, profiles/r04a_mfma_*_rate*.txt)")
         return r
 
-    from tissue_image_processing_amd import prediction_local as plm
+    def unet_modes_record():
+        """The network's forward pass in every arithmetic mode, timed in THIS run on one frame in flight (events on torch's stream,
+        median of 3 after one warm-up): the headline mode next to the 16-significand-bit bf16x3 of round 3, the six-product bf16x6
+        and MIOpen's float32 convolutions -- the float32-equivalent cross-references of the headline's figure."""
+        from tissue_image_processing_amd.prediction_local import SegmentationPredictor
+        _lib.init(local_rank)
+        pred = SegmentationPredictor(None, (2, X, Y), device=local_rank)
+        xin = torch.rand((1, 2) + tuple(plm.find_desired_shape(X, Y)), device=torch.device("cuda", local_rank))
+        keep = os.environ.get("TISSUE_HIP_UNET_ARITH")
+        out = {}
+        try:
+            for mode in ("f16x3", "bf16x3", "bf16x6", "miopen"):
+                os.environ["TISSUE_HIP_UNET_ARITH"] = mode
+                pred.model.forward(xin)
+                ms = []
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    pred.model.forward(xin)
+                    e1.record()
+                    e1.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                info = dict(plm.unet_arithmetic())
+                out[mode] = {"forward_ms": float(np.median(ms)), "ran_as": pred.model.last_mode,
+                             "float32_equivalent": bool(info.get("float32_equivalent", mode == "miopen")),
+                             "useful_tflops": pred.model.flops(int(xin.shape[2]), int(xin.shape[3])) / (float(np.median(ms)) / 1e3) / 1e12}
+        finally:
+            if keep is None:
+                os.environ.pop("TISSUE_HIP_UNET_ARITH", None)
+            else:
+                os.environ["TISSUE_HIP_UNET_ARITH"] = keep
+        return out
+
+    unet_mode = plm._unet_mode()
     wl_names = {
         "projection": "surface_projection",
         "classical": "surface_projection+watershed_segmentation+cell_tables",
@@ -715,6 +781,9 @@ def main():
         second = run_leg(wl2, threads_for(wl2, st2), st2, 8 if wl2 == "classical" else 3,
                          pcie_steps if pcie_steps is not None else (24 if wl2 == "classical" else 6))
     del st, st_flip
+    unet_modes = None
+    if rank == 0 and workload == "unet" and unet_mode != "miopen" and os.environ.get("TIP_BENCH_NO_MODES") != "1":
+        unet_modes = unet_modes_record()
 
     def leg_object(lg):
         """Everything one leg measured, as a JSON object."""
@@ -767,6 +836,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": head["workload"], "value_is": workload,
+                       "unet_arithmetic": plm.unet_arithmetic()["mode"] if workload == "unet" and unet_mode != "miopen" else None,
+                       "parity": ("U2 (the trained network, pl.py:31-72 + model.load_weights) is UNPINNED: no TensorFlow and no trained weights in "
+                                  "the container, the reference ships none -- random-init weights; the kernels are checked against the float64 "
+                                  "evaluation of the same layers (1e-5), every other stage against reference-generated goldens, bit for bit")
+                       if workload == "unet" else "every stage pinned by reference-generated goldens, bit for bit",
                        "baseline_config": ("configs[2]: 2048x2048 z=30 single frame, full pipeline (projection -> filter -> U-Net seg -> "
                                            "watershed/CCL)") if workload == "unet" else "the classical variant of configs[2] (no network)",
                        "frames_per_step": world, "frames_in_flight_per_gpu": leg["nthreads"], "includes_h2d_upload": False,
@@ -782,6 +856,8 @@ def main():
             out[second["workload"]] = dict(leg_object(second), note="secondary leg, timed right after the headline leg in the same process")
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if unet_modes is not None:
+            out["unet_arithmetic_modes"] = unet_modes
         print(json.dumps(out), flush=True)
         wd = leg["diag"] if workload == "unet" else (second["diag"] if second is not None and second["workload"] == "unet" else None)
         if wd and not all(v is None or v["all_two_valued"] for v in wd.values()):

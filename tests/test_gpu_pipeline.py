@@ -178,3 +178,30 @@ def test_movie_tracks_vs_oracle_at_512_with_rounds(monkeypatch, golden_taps, ora
     print("512^2 x %d frames: %d sites, labels per frame %s (%.1f per site), ids carried over %s, tracks %d, length histogram 1..%d: %s"
           % (T, n_sites, [len(i) for i in ids], len(ids[0]) / n_sites, carried, all_ids.max(), T, lengths.tolist()))
     assert all_ids.max() < sum(len(i) for i in ids)          # some tracks do continue
+
+
+def test_movie_rounds_do_not_leak_device_memory():
+    """process_movie calls the backend once per round; the backend's worker threads, their library contexts (stream, workspace
+    pool) and pipeline buffers persist across rounds and are released by close(): free device memory stays flat over many rounds
+    (round 3 created `inflight` fresh contexts per round and never released them)."""
+    import torch
+    from tissue_image_processing_amd import synthetic, movie
+    Z, Y, X = 6, 256, 256
+    st = synthetic.make_stack(Z, Y, X, seed=3)
+    torch.cuda.synchronize()
+    free_start = torch.cuda.mem_get_info(0)[0]
+    backend = movie.GpuFrameBackend(2, Z, Y, X, device=0, inflight=3)
+    frees = []
+    for rnd in range(24):
+        out = backend.process_frames([3 * rnd, 3 * rnd + 1, 3 * rnd + 2], lambda t: st)
+        assert sorted(out) == [3 * rnd, 3 * rnd + 1, 3 * rnd + 2]
+        for t in list(backend.labels):
+            backend.labels.pop(t).free()
+        torch.cuda.synchronize()
+        frees.append(torch.cuda.mem_get_info(0)[0])
+    assert len(backend._workers) == 3
+    # after the first rounds have sized the workspace pools nothing grows any more
+    assert max(frees[4:]) - min(frees[4:]) <= 8 << 20, [f >> 20 for f in frees]
+    backend.close()
+    torch.cuda.synchronize()
+    assert free_start - torch.cuda.mem_get_info(0)[0] <= 64 << 20        # the contexts' pools and the pipelines' buffers are back

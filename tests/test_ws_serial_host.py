@@ -37,6 +37,16 @@ def test_serial_flood_equals_reference_goldens(case):
     assert np.array_equal(out, g[case + "_labels"]), case
 
 
+def test_serial_flood_on_non_adjacent_ties():
+    """images whose only value ties are between non-marker pixels that share a neighbour (diagonals, distance two): skimage's
+    push-age order decides them (tools/make_goldens_ties.py keeps only cases where a raster order gets it wrong)"""
+    g = np.load(os.path.join(G, "watershed_diag_ties.npz"))
+    for k in range(6):
+        img = g["img%d" % k]
+        assert np.array_equal(serial_flood(img, markers_of(img)), g["labels%d" % k]), k
+        assert np.array_equal(orc.watershed(img), g["labels%d" % k]), k
+
+
 def test_serial_flood_with_the_reference_markers():
     g = np.load(os.path.join(G, "watershed.npz"))
     out = serial_flood(g["i2_blurred"], g["i2_markers"])

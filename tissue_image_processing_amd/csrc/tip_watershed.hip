@@ -14,9 +14,13 @@
 // If the tile rounds, the per-component endgame and the wide pass all stall (plateaus larger than any certificate), the
 // rest is one serial dependency chain and is finished by the host stage flood_keyed_finish (tip_ws_serial.hip) with the
 // same pop-time rule, which keeps the result identical to the serial flood for any image whose non-marker pixels carry
-// distinct values.  Mode A orders equal values between non-marker neighbours by raster index, the serial heap by push
-// age: `flags` bit0 reports that such ties were met, and unless the caller chose the fast policy (TIP_WS_TIES=fast) such
-// an image is flooded by the exact serial replay flood_exact instead (bit2).
+// DISTINCT values -- that is the guarantee of mode A.  Mode A orders equal values by raster index, the serial heap by push
+// age.  Ties are looked for where they can matter locally -- between non-marker pixels that are 4-neighbours or share a
+// 4-neighbour (diagonals, distance two: a pulled pixel between them sees one before the other) -- `flags` bit0 reports them,
+// and unless the caller chose the fast policy (TIP_WS_TIES=fast) such an image is flooded by the exact serial replay
+// flood_exact instead (bit2).  Equal values between pixels further apart can still matter through a CHAIN of pulled pixels
+// (a pocket enclosed by lines floods at once); float landscapes do not produce such exact ties away from plateaus, integer
+// landscapes trip the local detector everywhere, and no such case is known -- but it is outside the guarantee.
 // Mode B handles two-valued images (pl.py:194 floods a {0,255} boundary image) EXACTLY: the pop order of the equal-keyed
 // markers follows from the array heap's mechanics (tip_heaporder.hip), everything after it is a FIFO, i.e. a
 // breadth-first search in generations whose pixels carry dense ranks (see the mode B section below).
@@ -188,6 +192,13 @@ __global__ void __launch_bounds__(256) k_ws_init_state(const double *__restrict_
         bool tie = false;
         if (x > 0 && v[i - 1] == h) tie = true;
         if (y > 0 && v[i - X] == h) tie = true;
+        // ... and between non-marker pixels that SHARE a neighbour (diagonals, distance two): a lower pixel between them that is
+        // enclosed by lines pops right after whichever of the two pops first ("pulled") and is then seen, or not, by the other
+        auto nm_eq = [&](int j) { return v[j] == h && flag[parent[j]] != 0; };
+        if (y > 0 && x > 0 && nm_eq(i - X - 1)) tie = true;
+        if (y > 0 && x + 1 < X && nm_eq(i - X + 1)) tie = true;
+        if (y > 1 && nm_eq(i - 2 * X)) tie = true;
+        if (x > 1 && nm_eq(i - 2)) tie = true;
         if (tie) info->ties = 1;
     }
 }

@@ -23,6 +23,66 @@ import ctypes
 import numpy as np
 
 
+class _Job(object):
+    """One process_frames call: a shared frame iterator the workers pull from."""
+
+    def __init__(self, it, frame_source, nworkers):
+        import threading
+        self.it, self.frame_source = it, frame_source
+        self.lock, self.done = threading.Lock(), threading.Semaphore(0)
+        self.out, self.errors = {}, []
+
+
+class _FrameWorker(object):
+    """A worker thread of GpuFrameBackend with its own library context and FramePipeline, alive until it is sent None."""
+
+    def __init__(self, backend):
+        import queue
+        import threading
+        self.backend = backend
+        self.jobs = queue.Queue()
+        self.thread = threading.Thread(target=self.run, daemon=True)
+        self.thread.start()
+
+    def join(self):
+        self.thread.join()
+
+    def run(self):
+        from . import _lib
+        from .pipeline import FramePipeline
+        b = self.backend
+        pipe, setup_error = None, None
+        try:
+            _lib.init(b.device)
+            pipe = FramePipeline(*b._shape, **b._kw)
+        except BaseException as e:
+            setup_error = e
+        try:
+            while True:
+                job = self.jobs.get()
+                if job is None:
+                    return
+                try:
+                    if setup_error is not None:
+                        raise setup_error
+                    while True:
+                        with job.lock:
+                            t = next(job.it, None)
+                        if t is None:
+                            break
+                        job.out[t] = b._process_with(pipe, t, job.frame_source(t))
+                except BaseException as e:      # a dead worker must fail the movie, not shorten it silently
+                    job.errors.append(e)
+                finally:
+                    job.done.release()
+        finally:
+            pipe = None                          # (its DeviceBuffers go back before the context that launched on them)
+            try:
+                _lib.load().tip_shutdown()
+            except Exception:
+                pass
+
+
 class GpuFrameBackend(object):
     """Per-frame compute on this rank's MI355X through FramePipeline.  What later stages need stays resident per owned
     frame: the int32 label map (tracker look-ups) and, when drift is estimated, the reference channel's projection plane
@@ -41,6 +101,7 @@ class GpuFrameBackend(object):
         self.inflight = max(1, int(inflight))
         self.labels = {}   # frame -> DeviceBuffer (int32 label map)
         self.planes = {}   # frame -> torch tensor (Y, X) float64 on this GPU
+        self._workers = []  # persistent worker threads (process_frames)
 
     def process_frame(self, t, stack_u16):
         return self._process_with(self.pipe, t, stack_u16)
@@ -49,36 +110,40 @@ class GpuFrameBackend(object):
         """All of this rank's frames, `inflight` at a time: worker threads, each with its own HIP stream, workspaces and
         FramePipeline (the library is re-entrant per thread), pull frames from a shared iterator -- one frame's host->device
         upload overlaps the other frames' kernels, and the latency-bound watershed of one overlaps the projection of
-        another.  frame_source(t) is called from the worker threads."""
+        another.  frame_source(t) is called from the worker threads.
+
+        The workers live as long as the backend (process_movie calls this once per round): a thread's library context -- its HIP
+        stream, workspace pool and order-statistic state -- and its pipeline buffers are created once and released by close(),
+        so a long movie neither re-allocates them every round nor piles up one context per round."""
         import threading
         frames = list(frames)
         if self.inflight <= 1 or len(frames) <= 1:
             return {t: self.process_frame(t, frame_source(t)) for t in frames}
-        from . import _lib
-        from .pipeline import FramePipeline
-        it, lock, out, errors = iter(frames), threading.Lock(), {}, []
+        n = min(self.inflight, len(frames))
+        while len(self._workers) < n:
+            self._workers.append(_FrameWorker(self))
+        job = _Job(iter(frames), frame_source, n)
+        for w in self._workers[:n]:
+            w.jobs.put(job)
+        for _ in range(n):
+            job.done.acquire()
+        if job.errors:
+            raise job.errors[0]
+        return job.out
 
-        def work():
-            try:
-                _lib.init(self.device)
-                pipe = FramePipeline(*self._shape, **self._kw)
-                while True:
-                    with lock:
-                        t = next(it, None)
-                    if t is None:
-                        return
-                    out[t] = self._process_with(pipe, t, frame_source(t))
-            except BaseException as e:      # a dead worker must fail the movie, not shorten it silently
-                errors.append(e)
+    def close(self):
+        """Ends the worker threads; each releases its pipeline buffers and its library context (tip_shutdown) on the way out."""
+        workers, self._workers = self._workers, []
+        for w in workers:
+            w.jobs.put(None)
+        for w in workers:
+            w.join()
 
-        threads = [threading.Thread(target=work) for _ in range(min(self.inflight, len(frames)))]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        if errors:
-            raise errors[0]
-        return out
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _process_with(self, p, t, stack_u16):
         from . import _lib
