@@ -819,13 +819,25 @@ def main():
         # direct correlation are useful (the rest multiplies the band's zeros); `frac` is the USEFUL rate over the dense FP32
         # MFMA peak (= the FP32 vector peak, 256 flop / clk / CU)
         valu = {}
-        for kname in ("score_fast_y", "score_fast_x"):
+        cfg = (os.environ.get("TIP_FAST_CFG") or "5,5").split(",")
+        for kname, which in (("score_fast_y", cfg[0]), ("score_fast_x", cfg[-1])):
             if kname in lg["iso"] and lg["iso"][kname][0]:
                 cnt_k, ms_k = lg["iso"][kname]
                 sec = ms_k / cnt_k / 1e3
                 useful = Z * Y * X * 482.0 / sec / 1e12
-                valu[kname] = {"bound": "mfma_fp32", "achieved": useful, "issued": Z * Y * X * 544.0 / sec / 1e12,
-                               "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": useful / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
+                if which == "5":
+                    # the fp16 tiles (csrc/tip_corr_f16.h): 17 K-steps of 16 positions x 3 piece products per output = 1632 flop issued
+                    # for the 482 of a direct correlation; the pass moves 2 V 4 bytes -- with the matrix work sixteen times cheaper it
+                    # is the memory system's turn, so both fractions are given
+                    issued = Z * Y * X * 1632.0 / sec / 1e12
+                    valu[kname] = {"bound": "mfma_f16 / hbm", "achieved": useful, "issued": issued, "peak": 2500.0, "unit": "TFLOP/s",
+                                   "frac": issued / 2500.0, "hbm_GBps": 2 * Z * Y * X * 4 / sec / 1e9,
+                                   "hbm_frac": 2 * Z * Y * X * 4 / sec / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_k / cnt_k,
+                                   "arithmetic": "float32 samples and taps split into two fp16 pieces, three products per term, float32 accumulation; "
+                                                 "`frac` = issued fp16 MFMA flops / dense peak"}
+                else:
+                    valu[kname] = {"bound": "mfma_fp32", "achieved": useful, "issued": Z * Y * X * 544.0 / sec / 1e12,
+                                   "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": useful / FP32_VALU_PEAK_TF, "avg_launch_ms": ms_k / cnt_k}
         o["roofline_valu"] = valu
         return o
 

@@ -109,6 +109,13 @@ TIP_API int tip_project_u16_dev(const uint16_t *czyx, int c, int z, int y, int x
                                 int ref_ch, int airyscan, int atoh_shift,
                                 const double *t05, const double *t1, const double *t2, const double *t30,
                                 double *proj, int64_t *zmap);
+/* diagnostics of the certified-argmax score passes on the fp16 matrix cores (csrc/tip_corr_f16.h; tests): ONE sigma-30 pass  */
+/* (241 float64 taps) of a host float32 volume along y (axis 1) or x (axis 2), data bounded by `clip`; flag bit 8: a sample   */
+/* beyond that range.  tip_mfma_f16_probe: out[t] = C + sum_k a[t][k] b[t][k] as one v_mfma_f32_32x32x16_f16 computes it -- */
+/* where the instruction rounds is what the certified error bound counts.                                                     */
+TIP_API int tip_score_pass_f16(const float *in, float *out, int z, int y, int x, int axis, const double *taps, int ntaps, float clip,
+                               int *flag);
+TIP_API int tip_mfma_f16_probe(const float *a, const float *b, const float *c, float *out, int ncase);
 /* sp.py:39-65, bin_size > 1: the score is reduced over bin x bin blocks (skimage block_reduce with */
 /* np.mean / np.var, numpy's float32 summation order) and resized back (skimage.transform.resize,   */
 /* order 1) before the argmax.  method: 0 'max_averages', 1 'max_std', 2 'multi_channel' (block     */

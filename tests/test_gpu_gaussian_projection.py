@@ -324,10 +324,138 @@ def test_every_fast_pass_variant_gives_the_same_zmap(mods, monkeypatch):
         monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
         proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
         monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE")
-        for cfg in (None, "3,3", "4,4", "4,3", "11616,11616", "1616,1616"):
+        for cfg in (None, "5,5", "3,4", "3,3", "4,4", "4,3", "5,4", "11616,11616", "1616,1616"):      # (5: the fp16 tiles, the default)
             if cfg:
                 monkeypatch.setenv("TIP_FAST_CFG", cfg)
             proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
             monkeypatch.delenv("TIP_FAST_CFG", raising=False)
             assert int((zmap != zmap_e).sum()) == 0, cfg
             np.testing.assert_array_equal(proj, proj_e)
+
+
+def _gauss30():
+    from oracle import oracle as orc
+    return np.asarray(orc.gaussian_kernel1d(30.0), dtype=np.float64)
+
+
+def _exact_pass(vol, w, axis):
+    """scipy's correlate1d(mode='nearest') of a float32 volume in float64 (not rounded): the real-number sum the bound refers to"""
+    r = len(w) // 2
+    pad = [(0, 0)] * 3
+    pad[axis] = (r, r)
+    v = np.pad(vol.astype(np.float64), pad, mode="edge")
+    out = np.zeros(vol.shape, np.float64)
+    n = vol.shape[axis]
+    for k in range(len(w)):
+        sl = [slice(None)] * 3
+        sl[axis] = slice(k, k + n)
+        out += w[k] * v[tuple(sl)]
+    return out
+
+
+def test_mfma_f16_rounding_structure_on_this_device():
+    """What the certified bound of csrc/tip_corr_f16.h counts: one v_mfma_f32_32x32x16_f16 adds its sixteen products to the
+    accumulator as TWO exactly-summed halves of eight (k 0..7, k 8..15), each rounded once (to nearest, ties to even) -- so a term
+    passes through two roundings per instruction, not sixteen.  Probed with exact power-of-two products (tools/ubench/
+    mfma_f16_rounding.hip prints the same cases); a device that rounds elsewhere fails here instead of silently voiding the bound."""
+    import ctypes
+    from tissue_image_processing_amd import _lib
+    lib = _lib.lib()
+    cases = []
+
+    def case(c, exps):                    # product k = 2^-exps[k] (None: no product)
+        a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        for k, e in enumerate(exps):
+            if e is not None:
+                a[k], b[k] = 2.0 ** -(e // 2), 2.0 ** -(e - e // 2)
+        cases.append((a, b, np.float32(c)))
+
+    case(1.0, [25] * 16)                                   # 0: exact sum 4 ulp
+    case(1.0, [26] * 16)                                   # 1: 2 ulp (two halves of 1 ulp each)
+    case(1.0, [27] * 16)                                   # 2: each half is HALF an ulp: ties to even -> 1 (one exact sum of 16 would give +1 ulp)
+    case(1.0, [26] * 8 + [None] * 8)                       # 3: a half of eight is summed exactly: +1 ulp (groups of four would tie away)
+    case(1.0, [None] * 8 + [26] * 8)                       # 4
+    case(1.0, [26 if k % 2 == 0 else None for k in range(16)])    # 5: four per half = half an ulp each -> 1
+    case(1.0, [25, 25, 25, 25] + [None] * 12)              # 6: +1 ulp
+    case(1.0, [26] * 6 + [None] * 10)                      # 7: 0.75 ulp in one half: +1 ulp to nearest (0 if the adder truncated)
+    # 8, 9: half an ulp plus a little (1/128, 1/16384 of an ulp): +1 ulp if the half-sum is exact before its one rounding
+    for extra in (3, 10):
+        a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        a[:8], b[:8] = 2.0 ** -13, 2.0 ** -14
+        a[0] = 2.0 ** -13 * (1 + 2.0 ** -extra)
+        cases.append((a, b, np.float32(1.0)))
+    a = np.stack([c[0] for c in cases]).astype(np.float32)
+    b = np.stack([c[1] for c in cases]).astype(np.float32)
+    cv = np.asarray([c[2] for c in cases], np.float32)
+    out = np.zeros(len(cases), np.float32)
+    _lib.check(lib.tip_mfma_f16_probe(_lib.ptr(a), _lib.ptr(b), _lib.ptr(cv), _lib.ptr(out), len(cases)))
+    ulps = (out.astype(np.float64) - 1.0) / 2.0 ** -23
+    print("mfma f16 probe, ulps above 1:", ulps.tolist())
+    assert ulps[:7].tolist() == [4.0, 2.0, 0.0, 1.0, 1.0, 0.0, 1.0]
+    assert ulps[7] in (0.0, 1.0)          # (either rounding mode of the half-sums is inside the 2 u the bound takes per rounding)
+    assert ulps[8] in (0.0, 1.0) and ulps[9] in (0.0, 1.0)
+
+
+@pytest.mark.parametrize("axis", [1, 2])
+def test_f16_score_pass_error_bound(axis):
+    """One sigma-30 pass on the fp16 matrix cores against the float64 sum: relative error below the 38.2 u the certification
+    assumes (measured: a few u), on data spanning the clip range, on a black-background volume whose blurred fringes decay through
+    thirty orders of magnitude (22 bits relative down to 2^-36 of the clip value, the absolute floor below), ragged extents;
+    a zero score means zero inputs."""
+    import ctypes
+    from tissue_image_processing_amd import _lib
+    lib = _lib.lib()
+    w = _gauss30()
+    assert len(w) == 241
+    rng = np.random.default_rng(5 + axis)
+    u = 2.0 ** -24
+    for shape, kind in (((2, 300, 333), "dense"), ((1, 520, 290), "fringes"), ((3, 64, 40), "small")):
+        clip = np.float32(3187.25)
+        if kind == "fringes":
+            vol = np.zeros(shape, np.float32)
+            vol[0, 255:259, 140:150] = clip                      # an isolated blob: its tails are all there is
+            vol[0, 10, 5] = np.float32(1e-20)                    # far below the floor, but not zero
+            vol = _exact_pass(vol, w, 1 if axis == 2 else 2).astype(np.float32)     # a first pass: tails of every magnitude
+        else:
+            vol = (rng.random(shape) ** 3 * clip).astype(np.float32)
+            vol[rng.random(shape) < 0.2] = 0
+        out = np.empty_like(vol)
+        flag = ctypes.c_int(0)
+        _lib.check(lib.tip_score_pass_f16(_lib.ptr(vol), _lib.ptr(out), shape[0], shape[1], shape[2], axis, _lib.ptr(w), 241,
+                                          ctypes.c_float(float(clip)), ctypes.byref(flag)))
+        assert flag.value == 0
+        ref = _exact_pass(vol, w, axis)
+        err = np.abs(out.astype(np.float64) - ref)
+        floor = float(clip) * 2.0 ** -47
+        rel = np.where(ref > 0, (err - floor).clip(0) / np.where(ref > 0, ref, 1), 0)
+        print("f16 score pass axis %d %s %s: max relative error %.2f u (beyond the absolute floor), max |error| %.3g"
+              % (axis, kind, shape, rel.max() / u, err.max()))
+        assert rel.max() < 38.2 * u
+        assert np.array_equal(out == 0, ref == 0)                # zero score <=> zero inputs
+    # a sample beyond the clip's range raises the flag instead of silently saturating
+    bad = np.full((1, 64, 64), 4.0 * 3187.25, np.float32)
+    flag = ctypes.c_int(0)
+    _lib.check(lib.tip_score_pass_f16(_lib.ptr(bad), _lib.ptr(np.empty_like(bad)), 1, 64, 64, axis, _lib.ptr(w), 241, ctypes.c_float(3187.25),
+                                      ctypes.byref(flag)))
+    assert flag.value & 8
+
+
+def test_black_background_zmap_is_exact(mods, monkeypatch):
+    """airyscan=True subtracts 10000 and clamps: large exactly-zero regions with blurred fringes of every magnitude around the signal.
+    The fp16 score tiles keep the certification meaningful there (relative accuracy down to 2^-36 of the clip value, zero scores only
+    from zero inputs): the z-map equals the all-exact path's."""
+    _, sp, _ = mods
+    rng = np.random.default_rng(12)
+    Z, Y, X = 9, 600, 700
+    st = np.full((2, Z, Y, X), 9000, np.uint16)                  # below the airyscan offset: zero after the subtraction
+    for _ in range(40):                                          # sparse bright blobs at random planes
+        z, y, x = int(rng.integers(0, Z)), int(rng.integers(0, Y - 12)), int(rng.integers(0, X - 12))
+        st[:, z, y:y + 12, x:x + 12] = 10000 + rng.integers(50, 4000, (2, 12, 12))
+        if z + 1 < Z:
+            st[:, z + 1, y:y + 12, x:x + 12] = 10000 + rng.integers(50, 4000, (2, 12, 12))
+    monkeypatch.setenv("TIP_PROJECT_EXACT_SCORE", "1")
+    proj_e, zmap_e = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=True, z_map=True)
+    monkeypatch.delenv("TIP_PROJECT_EXACT_SCORE")
+    proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=True, z_map=True)
+    assert int((zmap != zmap_e).sum()) == 0
+    np.testing.assert_array_equal(proj, proj_e)

@@ -10,6 +10,8 @@
 #include "tip_slide.h"
 #include "tip_preblur.h"
 #include "tip_corr_mfma2.h"
+#include "tip_corr_f16.h"
+#include <atomic>
 #include "tip_manifold.h"
 #include <algorithm>
 #include <cstdlib>
@@ -547,10 +549,10 @@ __global__ void __launch_bounds__(256) k_mask_wmax_fused(const float *__restrict
 // 4: 0.76 / 0.69 ms; whole classical pipeline 155 / 166.6 / 169.4 frames/s for (VALU, VALU) / (3, 3) / (3, 4), and
 // 242.7 / 249.8 / 252.2 with four frames in flight.
 #ifndef FAST_CFG_Y
-#define FAST_CFG_Y 3
+#define FAST_CFG_Y 5
 #endif
 #ifndef FAST_CFG_X
-#define FAST_CFG_X 4
+#define FAST_CFG_X 5
 #endif
 
 static int cu_count()
@@ -623,10 +625,32 @@ static int launch_mfma2(const float *in, float *out, int Zs, int Y, int X, const
     return TIP_OK;
 }
 
+// ... on the fp16 matrix cores with split operands (tip_corr_f16.h): radius 120 (sigma 30), data bounded by the clip value
 template <int AXIS>
-static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t)
+static int launch_f16(const float *in, float *out, int Zs, int Y, int X, const TapsF &t, const ClipInfo *clip, int *range_flag)
+{
+    constexpr int R8 = 15, NPOS = HF_TO + 16 * R8, PITCH = ((NPOS / 8) | 1) * 8, WROWS = 2 * (R8 + 2) + 3;
+    const size_t lds = (size_t)2 * HF_LN * PITCH * 2 + (size_t)2 * WROWS * 8 * 16;
+    auto k = k_corr_long_f16<AXIS, R8>;
+    static std::atomic<unsigned> attr_done[64];
+    const int dev = ctx().device >= 0 && ctx().device < 64 ? ctx().device : 0;
+    if (!(attr_done[dev].load(std::memory_order_acquire) & (1u << AXIS))) {
+        TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[dev].fetch_or(1u << AXIS, std::memory_order_release);
+    }
+    const dim3 grid(cdiv(AXIS == 1 ? X : Y, HF_LN), cdiv(AXIS == 1 ? Y : X, HF_TO), Zs);
+    if (grid.y > 65535 || grid.z > 65535) return fail(TIP_ERR_ARG, "f16 score pass: grid too large");
+    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(HF_NW * 64), lds, in, out, Zs, Y, X, t, &clip->p95, &clip->has, range_flag);
+    return TIP_OK;
+}
+
+template <int AXIS>
+static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int X, const TapsF &t, const ClipInfo *clip = nullptr,
+                       int *range_flag = nullptr)
 {
     const int r = t.n >> 1;
+    if (cfg == 5 && (r != 120 || !clip || !range_flag)) cfg = AXIS == 1 ? 3 : 4;          // the fp16 tiles: sigma 30 on clipped data only
+    if (cfg == 5) return launch_f16<AXIS>(in, out, Zs, Y, X, t, clip, range_flag);
     if ((cfg == 3 || cfg == 4) && (r < 8 || r > 120 || r % MF_SEG)) cfg = 11616;   // the MFMA tiles need radius % 8 == 0 (sigma 30: 120)
     if (cfg == 3) return launch_mfma<AXIS>(in, out, Zs, Y, X, t);
     if (cfg == 4) return launch_mfma2<AXIS>(in, out, Zs, Y, X, t);
@@ -652,12 +676,19 @@ static int launch_fast(int cfg, const float *in, float *out, int Zs, int Y, int 
 // are not (top two planes closer than ~1.2e-5 relative: the lines where the surface crosses between planes) are
 // recomputed in exact scipy arithmetic from the z-passed volume, for the candidate planes only.
 #define CERT_EPS (96.0f * 5.9604644775390625e-8f)
+// absolute part of the fast passes' error: none for the float32 tiles (relative down to underflow); the fp16 tiles keep 22 bits
+// relative down to 2^-36 of the clip value and are off by at most clip 2^-47 below that (tip_corr_f16.h) -- 2^-44 here
+__device__ __forceinline__ float cert_abs(const ClipInfo *clip)
+{
+    return (clip && clip->has) ? clip->p95 * 5.684341886080802e-14f + 1e-30f : 1e-30f;
+}
 
 // four adjacent pixels per thread (one float4 per plane): enough bytes in flight to stream the score volume
 __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict__ score, int Z, long P, int *__restrict__ best_z,
-                                                        int *__restrict__ unc_list, int *__restrict__ unc_count)
+                                                        int *__restrict__ unc_list, int *__restrict__ unc_count, const ClipInfo *clip)
 {
     __shared__ int s_cnt[4], s_base;
+    const float dabs = cert_abs(clip);
     const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const bool vec = p0 + 4 <= P && (P & 3) == 0;
     float b1[4], b2[4];
@@ -687,7 +718,7 @@ __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict_
         if (p0 + k >= P) continue;
         best_z[p0 + k] = z1[k];
         // b1 == 0: every plane is exactly zero in the fast pass, hence (no underflow for uint16-derived data) in the exact one
-        const bool certain = (b1[k] == 0.f) || (Z == 1) || (b1[k] * (1.f - CERT_EPS) > b2[k] * (1.f + CERT_EPS) + 1e-30f);
+        const bool certain = (b1[k] == 0.f) || (Z == 1) || (b1[k] * (1.f - CERT_EPS) - dabs > b2[k] * (1.f + CERT_EPS) + dabs);
         if (!certain) unc |= 1u << k;
     }
     // append with one atomic per block (not per pixel: same-address atomics serialise in L2)
@@ -717,8 +748,9 @@ __global__ void __launch_bounds__(256) k_argmax_certify(const float *__restrict_
 constexpr int FIX_UL = 16;
 __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restrict__ zvol, const float *__restrict__ score, int Z, int Y,
                                                           int X, Taps taps, const int *__restrict__ unc_list,
-                                                          const int *__restrict__ unc_count, int *__restrict__ best_z)
+                                                          const int *__restrict__ unc_count, int *__restrict__ best_z, const ClipInfo *clip)
 {
+    const float dabs = cert_abs(clip);
     __shared__ float c[256];
     __shared__ float sfast[64];
     __shared__ float sexact[64];
@@ -738,9 +770,9 @@ __global__ void __launch_bounds__(256) k_argmax_exact_fix(const float *__restric
         __syncthreads();
         float smax = sfast[0];
         for (int z = 1; z < Z; ++z) smax = fmaxf(smax, sfast[z]);
-        const float thr = smax * (1.f - CERT_EPS);
+        const float thr = smax * (1.f - CERT_EPS) - dabs;
         for (int z = 0; z < Z; ++z) {
-            const bool cand = sfast[z] * (1.f + CERT_EPS) + 1e-30f >= thr;  // block-uniform
+            const bool cand = sfast[z] * (1.f + CERT_EPS) + dabs >= thr;  // block-uniform
             if (!cand) { if (threadIdx.x == 0) sexact[z] = -1.f; continue; }
             const float *vol = zvol + (long)z * P;
             if (threadIdx.x < 2 * r + 1) {
@@ -1123,20 +1155,25 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         {   // fast y pass B -> A, fast x pass A -> D   (B, the exact z-passed volume, is kept for the exact fix-up)
             int cy = FAST_CFG_Y, cx = FAST_CFG_X;
             if (tuning().fast_cfg_y >= 0) { cy = tuning().fast_cfg_y; cx = tuning().fast_cfg_x >= 0 ? tuning().fast_cfg_x : cx; }  // tuning hook TIP_FAST_CFG: NW*100+NP per pass
-            if ((rc = launch_fast<1>(cy, (const float *)B, A, Zs, Y, X, f30))) return rc;
-            if ((rc = launch_fast<2>(cx, (const float *)A, D, Zs, Y, X, f30))) return rc;
+            // (the fp16 tiles, cfg 5, take the clip value: their samples are scaled into fp16's range by it, and the volume B --
+            //  convex combinations of clipped voxels -- is bounded by it; err bit 8 would report a sample beyond that range)
+            if ((rc = launch_fast<1>(cy, (const float *)B, A, Zs, Y, X, f30, clip, err))) return rc;
+            if ((rc = launch_fast<2>(cx, (const float *)A, D, Zs, Y, X, f30, clip, err))) return rc;
         }
         TIP_HIP(hipMemsetAsync(uncn, 0, sizeof(int), c.stream));
-        TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(cdiv(P, 4), 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn);
+        TIP_LAUNCH("argmax_certify", k_argmax_certify, dim3(cdiv(cdiv(P, 4), 256)), dim3(256), 0, (const float *)D, Zs, P, bestz, unc, uncn,
+                   (const ClipInfo *)clip);
         TIP_LAUNCH("argmax_exact_fix", k_argmax_exact_fix, dim3(8192), dim3(256), 0, (const float *)B, (const float *)D, Zs, Y, X,
-                   k30, (const int *)unc, (const int *)uncn, bestz);
+                   k30, (const int *)unc, (const int *)uncn, bestz, (const ClipInfo *)clip);
         TIP_LAUNCH("emit_zmaps", k_emit_zmaps, dim3(cdiv(P, 256)), dim3(256), 0, (const int *)bestz, Zs, P, min_z, atoh_shift, zsel,
                    zsel_a, zmap, err);
         if (tuning().project_debug) {
-            int hn = 0;
+            int hn = 0, he = 0;
             TIP_HIP(hipMemcpyAsync(&hn, uncn, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TIP_HIP(hipMemcpyAsync(&he, err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
             TIP_HIP(hipStreamSynchronize(c.stream));
             fprintf(stderr, "certified argmax: %d of %ld pixels recomputed exactly\n", hn, P);
+            if (he & 8) return fail(TIP_ERR_HIP, "score pass: a sample beyond the clip value's range reached the fp16 tiles");
         }
     } else {
         if ((rc = correlate1d_dev(B, A, 0, Zs, Y, X, 1, k30, 0))) return rc;
@@ -1188,6 +1225,7 @@ int project_dev(const uint16_t *czyx, int C, int Z, int Y, int X, int zlo, int z
         TIP_HIP(hipMemcpyAsync(&h, err, sizeof(int), hipMemcpyDeviceToHost, c.stream));
         TIP_HIP(hipStreamSynchronize(c.stream));
         if (h & 2) return fail(TIP_ERR_HIP, "build_manifold: a pixel without a visited neighbour (upstream raises TypeError here)");
+        if (h & 8) return fail(TIP_ERR_HIP, "score pass: a sample beyond the clip value's range reached the fp16 tiles");
         if (h)
             return fail(TIP_ERR_INDEX, "chosen z index out of bounds for the %d-plane mask (min_z=%d, atoh_shift=%d): "
                                        "the reference raises IndexError here (sp.py:62,68-69)", Zs, min_z, atoh_shift);
@@ -1290,6 +1328,69 @@ int tip_project_u16_binned(const uint16_t *czyx, int c, int z, int y, int x, int
 }
 
 // sp.py:87-165 on its own: score float32 (z, y, x) host -> int64 (y, x) plane map
+// ---- diagnostics of the fp16 score tiles (tests) ---------------------------------------------------------------------------------
+__global__ void k_set_clip(ClipInfo *c, float v) { c->has = 1; c->p95 = v; c->p95d = (double)v; }
+
+// one sigma-30 pass of tip_corr_f16.h on HOST float32 volumes (z, y, x): axis 1 = along y, 2 = along x; taps = 241 symmetric float64
+// weights (radius 120); clip = the bound of the data (the scaling follows from it).  flag: bit 8 = a sample beyond the range.
+int tip_score_pass_f16(const float *in, float *out, int z, int y, int x, int axis, const double *taps, int ntaps, float clip, int *flag)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!in || !out || !taps || !flag || z < 1 || y < 1 || x < 1 || (axis != 1 && axis != 2) || ntaps != 241 || !(clip > 0.f))
+        return fail(TIP_ERR_ARG, "tip_score_pass_f16: bad arguments (radius 120 only)");
+    const size_t V = (size_t)z * y * x;
+    WsGuard ws;
+    float *di = ws.get<float>(V), *dout = ws.get<float>(V);
+    ClipInfo *ci = ws.get<ClipInfo>(1);
+    int *df = ws.get<int>(1);
+    if (!di || !dout || !ci || !df) return TIP_ERR_NOMEM;
+    TapsF t;
+    t.n = ntaps;
+    for (int i = 0; i < 256; ++i) t.w[i] = i < ntaps ? (float)taps[i] : 0.f;
+    TIP_HIP(hipMemcpyAsync(di, in, V * 4, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipMemsetAsync(df, 0, sizeof(int), c.stream));
+    hipLaunchKernelGGL(k_set_clip, dim3(1), dim3(1), 0, c.stream, ci, clip);
+    int rc = axis == 1 ? launch_f16<1>(di, dout, z, y, x, t, ci, df) : launch_f16<2>(di, dout, z, y, x, t, ci, df);
+    if (rc) return rc;
+    TIP_HIP(hipMemcpyAsync(out, dout, V * 4, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipMemcpyAsync(flag, df, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
+// How v_mfma_f32_32x32x16_f16 rounds, on THIS device (the certified bound of tip_corr_f16.h counts two roundings per instruction:
+// the sixteen products enter the accumulator as two exactly-summed halves).  Every row of A / column of B is the same; case t has
+// C = c[t] and product k = a[t][k] b[t][k]; out[t] = any output element.
+__global__ void k_mfma_f16_probe(const float *a, const float *b, const float *c, float *out, int ncase)
+{
+    const int h = threadIdx.x >> 5;
+    for (int t = 0; t < ncase; ++t) {
+        f16x8 fa, fb;
+        for (int e = 0; e < 8; ++e) { fa[e] = (_Float16)a[t * 16 + 8 * h + e]; fb[e] = (_Float16)b[t * 16 + 8 * h + e]; }
+        f32x16 acc;
+        for (int q = 0; q < 16; ++q) acc[q] = c[t];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+        if (threadIdx.x == 0) out[t] = acc[0];
+    }
+}
+int tip_mfma_f16_probe(const float *a, const float *b, const float *cvals, float *out, int ncase)
+{
+    Ctx &c = ctx();
+    if (!c.stream) return TIP_ERR_HIP;
+    if (!a || !b || !cvals || !out || ncase < 1 || ncase > 256) return fail(TIP_ERR_ARG, "tip_mfma_f16_probe: bad arguments");
+    WsGuard ws;
+    float *da = ws.get<float>((size_t)ncase * 16), *db = ws.get<float>((size_t)ncase * 16), *dc = ws.get<float>(ncase), *dout = ws.get<float>(ncase);
+    if (!da || !db || !dc || !dout) return TIP_ERR_NOMEM;
+    TIP_HIP(hipMemcpyAsync(da, a, (size_t)ncase * 64, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipMemcpyAsync(db, b, (size_t)ncase * 64, hipMemcpyHostToDevice, c.stream));
+    TIP_HIP(hipMemcpyAsync(dc, cvals, (size_t)ncase * 4, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_mfma_f16_probe, dim3(1), dim3(64), 0, c.stream, (const float *)da, (const float *)db, (const float *)dc, dout, ncase);
+    TIP_HIP(hipMemcpyAsync(out, dout, (size_t)ncase * 4, hipMemcpyDeviceToHost, c.stream));
+    TIP_HIP(hipStreamSynchronize(c.stream));
+    return TIP_OK;
+}
+
 int tip_build_manifold_f32(const float *score, int z, int y, int x, int64_t *chosen)
 {
     Ctx &c = ctx();
