@@ -55,7 +55,7 @@ __device__ __forceinline__ HfScale hf_scale(const float *clip_p95, const int *cl
 template <int AXIS, int R8>
 __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X,
                                                                   TapsF taps, const float *__restrict__ clip_p95, const int *__restrict__ clip_has,
-                                                                  int *__restrict__ range_flag)
+                                                                  int *__restrict__ range_flag, int tiles_ln, int tiles_pos, int xcd_bands)
 {
     constexpr int r = 8 * R8, NPOS = HF_TO + 2 * r, S = R8 + 2;           // S K-steps per 32-output row tile, S + 2 per wave
     constexpr int PCH = (NPOS / 8) | 1, PITCH = PCH * 8;                   // row pitch: an odd number of 16-byte chunks (in fp16 elements)
@@ -64,7 +64,21 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
     _Float16 *sB_hi = reinterpret_cast<_Float16 *>(hf_smem), *sB_lo = sB_hi + HF_LN * PITCH;
     uint4 *sW_hi = reinterpret_cast<uint4 *>(sB_lo + HF_LN * PITCH), *sW_lo = sW_hi + WROWS * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lx = blockIdx.x, py = blockIdx.y, z = blockIdx.z;
+    // block -> tile.  The grid is (tiles of a plane, planes).  y pass: line tiles (32-column strips) fastest -- the blocks in flight cover
+    // whole rows, and the tiles that share a halo (py +- 1: tiles_ln blocks apart, a multiple of eight) sit on one XCD's L2.  x pass: a
+    // line tile is a band of 32 rows and the position tiles of a band lie side by side in memory, so the blocks of ONE XCD (block b runs
+    // on XCD b % 8) walk a band's position tiles one after the other: whole rows again, halo neighbours on one L2 (with the line tiles
+    // fastest the blocks in flight read 2 KB out of every 8 KB row: 0.52 ms against the y pass's 0.40).
+    const int z = blockIdx.y;
+    int lx, py;
+    if (AXIS == 2 && xcd_bands) {
+        const int b = blockIdx.x, k = b & 7, j = b >> 3;
+        py = j % tiles_pos;
+        lx = k + 8 * (j / tiles_pos);
+    } else {
+        lx = blockIdx.x % tiles_ln;
+        py = blockIdx.x / tiles_ln;
+    }
     const int p0 = py * HF_TO, l0 = lx * HF_LN;
     const long P = (long)Y * X;
     const float *src = in + (long)z * P;
@@ -104,36 +118,30 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
     };
     constexpr int NG = NPOS / 8;                                  // position groups of eight (62)
     if (AXIS == 2) {
-        // unit = (row, four consecutive positions): consecutive lanes take consecutive 16-byte pieces of one row (a lane per 32 bytes
-        // asked for every cache line twice: 0.52 ms against the y pass's 0.40), written as two 8-byte pieces
-        constexpr int NQ = NPOS / 4;                              // quads per line (124)
-        constexpr int NIT = (HF_LN * NQ + HF_NW * 64 - 1) / (HF_NW * 64);
-        hf_f32x4 ld[NIT];
+        // unit = (row, position group): consecutive lanes take consecutive groups of one row (32 contiguous bytes each; a lane per
+        // 16 bytes with 8-byte LDS writes measured slower)
+        constexpr int NIT = (HF_LN * NG + HF_NW * 64 - 1) / (HF_NW * 64);
+        hf_f32x4 ld[NIT][2];
         const bool vec = (X & 3) == 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int unit = it * (HF_NW * 64) + tid, line = unit / NQ, q = unit - line * NQ;
+            const int unit = it * (HF_NW * 64) + tid, line = unit / NG, g = unit - line * NG;
             const float *row = src + (long)min(l0 + min(line, HF_LN - 1), Y - 1) * X;
-            const int x0 = p0 - r + 4 * q;
-            if (vec && x0 >= 0 && x0 + 4 <= X) ld[it] = *reinterpret_cast<const hf_f32x4 *>(row + x0);
-            else ld[it] = hf_f32x4{row[clampi(x0, 0, X - 1)], row[clampi(x0 + 1, 0, X - 1)], row[clampi(x0 + 2, 0, X - 1)], row[clampi(x0 + 3, 0, X - 1)]};
+            const int x0 = p0 - r + 8 * g;
+            if (vec && x0 >= 0 && x0 + 8 <= X) {
+                ld[it][0] = *reinterpret_cast<const hf_f32x4 *>(row + x0);
+                ld[it][1] = *reinterpret_cast<const hf_f32x4 *>(row + x0 + 4);
+            } else {
+                ld[it][0] = hf_f32x4{row[clampi(x0, 0, X - 1)], row[clampi(x0 + 1, 0, X - 1)], row[clampi(x0 + 2, 0, X - 1)], row[clampi(x0 + 3, 0, X - 1)]};
+                ld[it][1] = hf_f32x4{row[clampi(x0 + 4, 0, X - 1)], row[clampi(x0 + 5, 0, X - 1)], row[clampi(x0 + 6, 0, X - 1)], row[clampi(x0 + 7, 0, X - 1)]};
+            }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int unit = it * (HF_NW * 64) + tid, line = unit / NQ, q = unit - line * NQ;
-            if (unit < HF_LN * NQ) {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float vs = ld[it][e] * sc.s;
-                    out_of_range |= !(vs < 40000.f);
-                    hi[e] = (_Float16)vs;
-                    lo[e] = (_Float16)((vs - (float)hi[e]) * 2048.f);
-                    if (vs > 0.f && hi[e] == (_Float16)0.f && lo[e] == (_Float16)0.f) lo[e] = __builtin_bit_cast(_Float16, (unsigned short)1);
-                }
-                *reinterpret_cast<uint2 *>(sB_hi + line * PITCH + 4 * q) = __builtin_bit_cast(uint2, hi);
-                *reinterpret_cast<uint2 *>(sB_lo + line * PITCH + 4 * q) = __builtin_bit_cast(uint2, lo);
+            const int unit = it * (HF_NW * 64) + tid, line = unit / NG, g = unit - line * NG;
+            if (unit < HF_LN * NG) {
+                const float v[8] = {ld[it][0][0], ld[it][0][1], ld[it][0][2], ld[it][0][3], ld[it][1][0], ld[it][1][1], ld[it][1][2], ld[it][1][3]};
+                split8(v, line, g);
             }
         }
     } else {

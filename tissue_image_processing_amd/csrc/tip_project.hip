@@ -638,9 +638,12 @@ static int launch_f16(const float *in, float *out, int Zs, int Y, int X, const T
         TIP_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[dev].fetch_or(1u << AXIS, std::memory_order_release);
     }
-    const dim3 grid(cdiv(AXIS == 1 ? X : Y, HF_LN), cdiv(AXIS == 1 ? Y : X, HF_TO), Zs);
-    if (grid.y > 65535 || grid.z > 65535) return fail(TIP_ERR_ARG, "f16 score pass: grid too large");
-    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(HF_NW * 64), lds, in, out, Zs, Y, X, t, &clip->p95, &clip->has, range_flag);
+    const int tiles_ln = cdiv(AXIS == 1 ? X : Y, HF_LN), tiles_pos = cdiv(AXIS == 1 ? Y : X, HF_TO);
+    if ((long)tiles_ln * tiles_pos > 0x7fffffffL || Zs > 65535) return fail(TIP_ERR_ARG, "f16 score pass: grid too large");
+    const dim3 grid((unsigned)(tiles_ln * tiles_pos), (unsigned)Zs);
+    const int xcd_bands = (AXIS == 2 && tiles_ln % 8 == 0) ? 1 : 0;
+    TIP_LAUNCH(AXIS == 1 ? "score_fast_y" : "score_fast_x", k, grid, dim3(HF_NW * 64), lds, in, out, Zs, Y, X, t, &clip->p95, &clip->has, range_flag,
+               tiles_ln, tiles_pos, xcd_bands);
     return TIP_OK;
 }
 
