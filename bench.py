@@ -726,8 +726,8 @@ def main():
 
     def unet_modes_record():
         """The network's forward pass in every arithmetic mode, timed in THIS run on one frame in flight (events on torch's stream,
-        median of 3 after one warm-up): the headline mode next to the 16-significand-bit bf16x3 of round 3, the six-product bf16x6
-        and MIOpen's float32 convolutions -- the float32-equivalent cross-references of the headline's figure."""
+        median of 3 after one warm-up): the headline mode next to the 16-significand-bit bf16x3 of round 3 and the six-product
+        bf16x6 -- the float32-equivalent cross-reference of the headline's figure."""
         from tissue_image_processing_amd.prediction_local import SegmentationPredictor
         _lib.init(local_rank)
         pred = SegmentationPredictor(None, (2, X, Y), device=local_rank)
@@ -735,7 +735,7 @@ def main():
         keep = os.environ.get("TISSUE_HIP_UNET_ARITH")
         out = {}
         try:
-            for mode in ("f16x3", "bf16x3", "bf16x6", "miopen"):
+            for mode in ("f16x3", "bf16x3", "bf16x6"):        # (MIOpen's float32 route: 181 ms when it has the device to itself, profiles/r02*)
                 os.environ["TISSUE_HIP_UNET_ARITH"] = mode
                 pred.model.forward(xin)
                 ms = []

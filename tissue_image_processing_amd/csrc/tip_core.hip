@@ -77,6 +77,23 @@ void *ws_alloc(size_t bytes)
     return p;
 }
 
+void *pinned_scratch(size_t bytes)
+{
+    Ctx &c = ctx();
+    if (c.pin_bytes >= bytes && c.pin_buf) return c.pin_buf;
+    if (c.pin_buf) { (void)hipHostFree(c.pin_buf); c.pin_buf = nullptr; c.pin_bytes = 0; }
+    const size_t want = bytes + (bytes >> 2) + 4096;          // (headroom: marker counts vary from frame to frame)
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(TIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", want);
+        return nullptr;
+    }
+    c.pin_buf = p;
+    c.pin_bytes = want;
+    return p;
+}
+
 void ws_free(void *p)
 {
     Ctx &c = ctx();
@@ -258,6 +275,7 @@ int tip_shutdown(void)
     for (auto &e : c->free_events) (void)hipEventDestroy(e);
     if (c->edge_event) (void)hipEventDestroy(c->edge_event);
     if (c->prep_ws) (void)hipFree(c->prep_ws);
+    if (c->pin_buf) (void)hipHostFree(c->pin_buf);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     g_ctx = nullptr;

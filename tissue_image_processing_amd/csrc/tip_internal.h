@@ -26,6 +26,8 @@ struct Ctx {
     long last_ws_other = 0;   // ... and its number of pixels that are neither the image's minimum nor its maximum
     hipEvent_t edge_event = nullptr;   // tip_wait_stream / tip_stream_wait_tip
     void *prep_ws = nullptr;           // order-statistic state of tip_unet_prepare_f64_dev (used on the caller's stream only)
+    void *pin_buf = nullptr;           // pinned host staging (the watershed's marker-order stage: counts down, pop order up)
+    size_t pin_bytes = 0;
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
@@ -34,6 +36,7 @@ struct Ctx {
 Ctx &ctx();                       // lazily initialised for device 0 unless tip_init() chose another
 int fail(int code, const char *fmt, ...);
 void *ws_alloc(size_t bytes);     // nullptr on failure (error text set)
+void *pinned_scratch(size_t bytes);   // this thread's pinned host staging buffer, grown as needed (nullptr on failure)
 void ws_free(void *p);
 
 struct WsGuard {                  // frees workspaces at scope exit

@@ -1055,6 +1055,176 @@ __global__ void __launch_bounds__(1024) k_mb_resolve_tail(unsigned long long *__
     if (threadIdx.x == 0 && left) info->unfinished = 1;   // only if the generation is inconsistent (never seen)
 }
 
+// ---- the generation loop without a host round trip per generation ------------------------------------------------------------------
+// The sizes of a generation live on the device (MbState); every kernel reads them there and walks its list with a grid-stride loop,
+// so the host queues several generations' launches back to back and looks at the state once per batch (13 generations on a U-Net
+// tail frame: two looks instead of thirteen synchronisations).  A generation after the last one is a handful of empty launches.
+struct MbState {
+    int ncur;        // pixels of the generation that pushes (its ranked list); generation 0: the markers push
+    int nnext;       // pixels pushed so far by this generation (append counter of the unordered list)
+    int keyspace;    // rank keys of the generation being ranked: 4 x ncur (generation 0: 4 x markers)
+    int gen;         // generations completed
+    int pcount[4];   // waiting-list counters of the resolve passes
+    int scan_total;  // (unused total of the key scan)
+};
+
+__global__ void k_mb_state_init(MbState *S, int keyspace0)
+{
+    S->ncur = 0; S->nnext = 0; S->keyspace = keyspace0; S->gen = 0; S->scan_total = 0;
+    for (int q = 0; q < 4; ++q) S->pcount[q] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_mb_push_list_dn(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
+                                                         const int *__restrict__ list, MbState *S, int *__restrict__ next, int Y, int X)
+{
+    __shared__ int s_items[4 * 256], s_count, s_base;
+    const BlockList bl{s_items, &s_count, &s_base};
+    const int nlist = S->ncur;
+    for (int j0 = blockIdx.x * blockDim.x; j0 < nlist; j0 += gridDim.x * blockDim.x) {      // (block-uniform trip count: barriers inside)
+        bl_init(bl);
+        const int i = j0 + threadIdx.x;
+        if (i < nlist) mb_push_from(st, cand, bl, list[i], Y, X);
+        bl_flush(bl, next, &S->nnext);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mb_flag_keys_dn(const unsigned long long *__restrict__ cand, const int *__restrict__ next,
+                                                         const MbState *S, int *__restrict__ flag)
+{
+    const int nnext = S->nnext;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nnext; i += gridDim.x * blockDim.x) flag[(unsigned)(cand[next[i]] >> 32)] = 1;
+}
+
+// exclusive scan of the key flags, length on the device: a fixed grid walks the 2048-element chunks; a block first needs the sum of all
+// chunks in front of its own, which it accumulates as it goes (its chunks are gridDim.x apart)
+constexpr int MBS_ITEMS = 8, MBS_CHUNK = 256 * MBS_ITEMS;
+__global__ void __launch_bounds__(256) k_mb_scan_chunks(const int *__restrict__ in, int *__restrict__ out, const MbState *S, int *__restrict__ csum)
+{
+    __shared__ int wsum[4];
+    const int n = S->nnext > 0 ? S->keyspace : 0;
+    for (int c0 = blockIdx.x; (long)c0 * MBS_CHUNK < n; c0 += gridDim.x) {
+        const long base = (long)c0 * MBS_CHUNK + (long)threadIdx.x * MBS_ITEMS;
+        int v[MBS_ITEMS], sum = 0;
+#pragma unroll
+        for (int i = 0; i < MBS_ITEMS; ++i) {
+            v[i] = base + i < n ? in[base + i] : 0;
+            sum += v[i];
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        int run = woff + inc - sum;
+#pragma unroll
+        for (int i = 0; i < MBS_ITEMS; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run += v[i];
+        }
+        if (threadIdx.x == 255) csum[c0] = run;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_mb_scan_add(int *__restrict__ out, const MbState *S, const int *__restrict__ csum)
+{
+    __shared__ int wsum[4];
+    __shared__ int s_off;
+    const int n = S->nnext > 0 ? S->keyspace : 0;
+    int off = 0, done_to = 0;                    // sum of csum[0 .. done_to)
+    for (int c0 = blockIdx.x; (long)c0 * MBS_CHUNK < n; c0 += gridDim.x) {
+        int part = 0;
+        for (int j = done_to + threadIdx.x; j < c0; j += 256) part += csum[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) s_off = off + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        off = s_off;
+        done_to = c0;
+        const long base = (long)c0 * MBS_CHUNK + (long)threadIdx.x * MBS_ITEMS;
+#pragma unroll
+        for (int i = 0; i < MBS_ITEMS; ++i)
+            if (base + i < n) out[base + i] += off;
+        __syncthreads();
+    }
+}
+
+// ranks of the generation; the key flags of the NEXT generation's key space (4 x this generation's pixels) are cleared on the way
+__global__ void __launch_bounds__(256) k_mb_assign_ranks_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                            const int *__restrict__ next, const MbState *S, const int *__restrict__ drank,
+                                                            int *__restrict__ list, int *__restrict__ kflag_next)
+{
+    const int nnext = S->nnext;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nnext; i += gridDim.x * blockDim.x) {
+        const int u = next[i];
+        const int r = drank[(unsigned)(cand[u] >> 32)];
+        st[u] = pack_st(0, r + 1);
+        list[r] = u;
+    }
+    const long nk = 4L * nnext;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) kflag_next[i] = 0;
+}
+
+// resolve pass p (0: the whole generation; else the waiting list of pass p - 1), device counts, grid-stride
+__global__ void __launch_bounds__(256) k_mb_resolve_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                       const int *__restrict__ list, MbState *S, int pass, const int *__restrict__ src,
+                                                       int Y, int X, int *__restrict__ pend)
+{
+    __shared__ int s_items[4 * 256], s_count, s_base;
+    const BlockList bl{s_items, &s_count, &s_base};
+    const int n = pass == 0 ? S->nnext : S->pcount[pass - 1];
+    for (int j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x) {
+        bl_init(bl);
+        const int j = j0 + threadIdx.x;
+        if (j < n) {
+            const int i = pass == 0 ? j : src[j];
+            const int p = list[i];
+            bool waiting = true;
+            for (int attempt = 0; attempt < 2 && waiting; ++attempt) waiting = !mb_try_resolve(st, cand, p, i + 1, Y, X);
+            if (waiting) bl_push(bl, i);
+        }
+        bl_flush(bl, pend, &S->pcount[pass]);
+        __syncthreads();
+    }
+}
+
+// the one-block tail of a generation, then the state moves on to the next generation
+__global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+                                                             const int *__restrict__ list, const int *__restrict__ pend, MbState *S, int last_pass,
+                                                             int Y, int X, WsInfo *info)
+{
+    const int n = S->pcount[last_pass];
+    volatile unsigned long long *vst = st;
+    int left = n;
+    for (int sweep = 0; sweep <= n && left > 0; ++sweep) {
+        int mine = 0;
+        for (int j = threadIdx.x; j < n; j += 1024) {
+            const int i = pend[j], p = list[i];
+            if (st_lab(vst[p]) != 0) continue;
+            if (!mb_try_resolve(vst, cand, p, i + 1, Y, X)) mine = 1;
+        }
+        __threadfence_block();
+        left = __syncthreads_count(mine);
+    }
+    if (threadIdx.x == 0) {
+        if (left) info->unfinished = 1;       // only if the generation is inconsistent (never seen)
+        const int nn = S->nnext;
+        S->ncur = nn;
+        S->keyspace = 4 * nn;
+        S->nnext = 0;
+        S->gen += nn > 0 ? 1 : 0;
+        for (int q = 0; q < 4; ++q) S->pcount[q] = 0;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ws_emit(const unsigned long long *__restrict__ st, int32_t *__restrict__ out, long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1184,58 +1354,63 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         TIP_LAUNCH("mb_push_counts", k_mb_push_counts, dim3(cdiv(X, 256), Y), dim3(256), 0, (const unsigned long long *)st,
                    (const int *)mrank, c_d, Y, X);
         {
-            std::vector<unsigned char> hc((size_t)M);
-            std::vector<uint32_t> hE((size_t)M);
-            TIP_HIP(hipMemcpyAsync(hc.data(), c_d, (size_t)M, hipMemcpyDeviceToHost, s));
+            // counts down, pop sequence up, through this thread's pinned staging buffer (asynchronous copies, no per-frame allocation)
+            const size_t order_off = ((size_t)M + 63) & ~(size_t)63;
+            unsigned char *pin = (unsigned char *)pinned_scratch(order_off + (size_t)M * 4);
+            if (!pin) return TIP_ERR_NOMEM;
+            uint32_t *horder = reinterpret_cast<uint32_t *>(pin + order_off);
+            TIP_HIP(hipMemcpyAsync(pin, c_d, (size_t)M, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipStreamSynchronize(s));
-            if ((rc = marker_pop_order(hc.data(), M, hE.data()))) return rc;
-            TIP_HIP(hipMemcpyAsync(order_d, hE.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
-            TIP_HIP(hipStreamSynchronize(s));   // hE goes out of scope
+            if ((rc = marker_pop_order(pin, M, horder))) return rc;
+            TIP_HIP(hipMemcpyAsync(order_d, horder, (size_t)M * 4, hipMemcpyHostToDevice, s));      // (the buffer is next touched after this frame's later synchronisations)
         }
         TIP_LAUNCH("mb_invert", k_mb_invert, dim3(cdiv(M, 256)), dim3(256), 0, (const unsigned *)order_d, E_d, (long)M);
         TIP_LAUNCH("mb_init", k_mb_init, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)mrank, (const unsigned *)E_d, cand, n);
-        // (b) generations
+        // (b) generations: sizes on the device (MbState), launches queued MB_BATCH generations at a time, one look at the state per batch
         int *cur_list = lists, *next_list = lists + n;     // next_list doubles as the unordered append buffer: the ranked
         int *unordered = parent;                            // list is written from a separate buffer (parent is free here)
-        long keyspace = 4L * M;
-        int ncur = 0;
-        for (int gen = 0;; ++gen) {
-            TIP_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
-            if (gen == 0)
-                TIP_LAUNCH("mb_push_markers", k_mb_push_markers, dim3(cdiv(X, 256), Y), dim3(256), 0, st, cand, unordered, counter, Y, X);
-            else
-                TIP_LAUNCH("mb_push_list", k_mb_push_list, dim3(cdiv(ncur, 256)), dim3(256), 0, st, cand, (const int *)cur_list, ncur,
-                           unordered, counter, Y, X);
-            int nnext = 0;
-            TIP_HIP(hipMemcpyAsync(&nnext, counter, sizeof(int), hipMemcpyDeviceToHost, s));
-            TIP_HIP(hipStreamSynchronize(s));
-            if (nnext == 0) break;
-            TIP_HIP(hipMemsetAsync(kflag, 0, (size_t)keyspace * sizeof(int), s));
-            TIP_LAUNCH("mb_flag_keys", k_mb_flag_keys, dim3(cdiv(nnext, 256)), dim3(256), 0, (const unsigned long long *)cand,
-                       (const int *)unordered, nnext, kflag);
-            if ((rc = exclusive_scan_i32(kflag, drank, keyspace, nullptr))) return rc;
-            TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks, dim3(cdiv(nnext, 256)), dim3(256), 0, st, (const unsigned long long *)cand,
-                       (const int *)unordered, nnext, (const int *)drank, next_list);
-            // fate of the generation: parallel passes that ping-pong the list of waiting pixels (no host round trip: every
-            // pass is launched for the worst case and reads its count on the device), then the one-block tail
-            constexpr int MB_PASSES = 3;     // (pixels wait only across collision fronts: the second pass is already nearly empty)
-            TIP_HIP(hipMemsetAsync(pcount, 0, (MB_PASSES + 1) * sizeof(int), s));
-            for (int pass = 0; pass < MB_PASSES; ++pass) {
-                int *dst = pass & 1 ? pendB : pendA;
-                const int *src = pass == 0 ? nullptr : (pass & 1 ? pendA : pendB);
-                TIP_LAUNCH("mb_resolve", k_mb_resolve, dim3(cdiv(pass == 0 ? nnext : std::max(1, nnext >> pass), 256)), dim3(256), 0, st,
-                           (const unsigned long long *)cand, (const int *)next_list, nnext, src, (const int *)(pcount + pass), Y, X,
-                           dst, pcount + pass + 1);
+        MbState *S = ws.get<MbState>(1);
+        const long nm = n - M;                              // non-marker pixels: the most a generation (and all of them together) can hold
+        const long keycap_later = 4L * nm + 4;
+        int *csum = ws.get<int>((size_t)(std::max<long>(4L * M, keycap_later) / MBS_CHUNK + 2));
+        if (!S || !csum) return TIP_ERR_NOMEM;
+        TIP_LAUNCH("mb_state_init", k_mb_state_init, dim3(1), dim3(1), 0, S, (int)std::min<long>(4L * M, 0x7fffffffL));
+        TIP_HIP(hipMemsetAsync(kflag, 0, (size_t)(4L * M) * sizeof(int), s));
+        constexpr int MB_BATCH = 8, MB_PASSES = 2;         // (pixels wait only across collision fronts: the second pass is already nearly empty, the tail takes what it leaves)
+        const int lgrid = (int)std::max<long>(1, std::min<long>(cdiv(nm, 256), 1024));      // fixed grids, grid-stride loops over device counts
+        MbState hS;
+        for (int gen = 0;;) {
+            for (int b = 0; b < MB_BATCH; ++b, ++gen) {
+                if (gen == 0)
+                    TIP_LAUNCH("mb_push_markers", k_mb_push_markers, dim3(cdiv(X, 256), Y), dim3(256), 0, st, cand, unordered, &S->nnext, Y, X);
+                else
+                    TIP_LAUNCH("mb_push_list", k_mb_push_list_dn, dim3(lgrid), dim3(256), 0, st, cand, (const int *)cur_list, S, unordered, Y, X);
+                TIP_LAUNCH("mb_flag_keys", k_mb_flag_keys_dn, dim3(lgrid), dim3(256), 0, (const unsigned long long *)cand, (const int *)unordered,
+                           (const MbState *)S, kflag);
+                const long keys = gen == 0 ? 4L * M : keycap_later;
+                const int sgrid = (int)std::max<long>(1, std::min<long>(cdiv(keys, MBS_CHUNK), 1024));
+                TIP_LAUNCH("mb_scan_chunks", k_mb_scan_chunks, dim3(sgrid), dim3(256), 0, (const int *)kflag, drank, (const MbState *)S, csum);
+                TIP_LAUNCH("mb_scan_add", k_mb_scan_add, dim3(sgrid), dim3(256), 0, drank, (const MbState *)S, (const int *)csum);
+                TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks_dn, dim3(lgrid), dim3(256), 0, st, (const unsigned long long *)cand,
+                           (const int *)unordered, (const MbState *)S, (const int *)drank, next_list, kflag);
+                // fate of the generation: parallel passes that ping-pong the list of waiting pixels, then the one-block tail, which
+                // also moves the state on to the next generation
+                for (int pass = 0; pass < MB_PASSES; ++pass) {
+                    int *dst = pass & 1 ? pendB : pendA;
+                    const int *src = pass == 0 ? nullptr : (pass & 1 ? pendA : pendB);
+                    TIP_LAUNCH("mb_resolve", k_mb_resolve_dn, dim3(pass == 0 ? lgrid : std::max(1, lgrid >> (2 * pass))), dim3(256), 0, st,
+                               (const unsigned long long *)cand, (const int *)next_list, S, pass, src, Y, X, dst);
+                }
+                TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail_dn, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
+                           (const int *)next_list, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), S, MB_PASSES - 1, Y, X, info);
+                std::swap(cur_list, next_list);
             }
-            TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
-                       (const int *)next_list, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), (const int *)(pcount + MB_PASSES), Y,
-                       X, info);
-            std::swap(cur_list, next_list);
-            ncur = nnext;
-            keyspace = 4L * nnext;
+            TIP_HIP(hipMemcpyAsync(&hS, S, sizeof hS, hipMemcpyDeviceToHost, s));
+            TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));      // (the same look: did every generation resolve?)
+            TIP_HIP(hipStreamSynchronize(s));
+            if (hS.ncur == 0) break;                        // the last generation pushed nothing: the flood is complete
+            if (gen > 4 * (Y + X) + 64) return fail(TIP_ERR_HIP, "watershed: the two-valued flood does not terminate");
         }
-        TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));
-        TIP_HIP(hipStreamSynchronize(s));
         if (h.unfinished != 0) return fail(TIP_ERR_HIP, "watershed: a generation of the two-valued flood did not resolve");
     } else if (h.n_markers > 0) {
         // everyday tile flavour (tuning hook TIP_WS_TILE): interior edge, halo, evaluated margin
