@@ -101,17 +101,19 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
     // ---- samples ('nearest' edges: clamped coordinates).  ALL of a thread's loads are issued before the first conversion (sixteen
     // 16-byte loads in flight: the block is bound by their latency otherwise -- eight dependent round trips to memory per tile cost ten
     // times the tile's MFMA time), then split and written as 16-byte pieces of [line][position] -----------------------------------------
-    bool out_of_range = false;
+    // (the staging is the kernel's vector-ALU load -- the matrix pipe is a quarter busy -- so the split is kept short: the range check is
+    //  one running maximum, and "a positive sample keeps a positive low piece" is an addend min(vs 2^120, 2^-24) of the low piece -- 2^-24
+    //  for every positive sample, 0 for zero: below fp16's resolution wherever the remainder is a normal number, the smallest subnormal
+    //  where the sample is lost otherwise: a zero score still means zero inputs; at most 2^-35 absolute in scaled units, inside the bound)
+    float vmax = 0.f;
     auto split8 = [&](const float (&v)[8], int line, int g) {
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float vs = v[e] * sc.s;
-            out_of_range |= !(vs < 40000.f);                      // (never for data bounded by the clip value; NaN too)
+            vmax = fmax_raw(vmax, vs);
             hi[e] = (_Float16)vs;
-            lo[e] = (_Float16)((vs - (float)hi[e]) * 2048.f);
-            // a positive sample below 2^-36 of the scaled range keeps the smallest positive low piece: a zero score means zero inputs
-            if (vs > 0.f && hi[e] == (_Float16)0.f && lo[e] == (_Float16)0.f) lo[e] = __builtin_bit_cast(_Float16, (unsigned short)1);
+            lo[e] = (_Float16)__builtin_fmaf(vs - (float)hi[e], 2048.f, fminf(vs * 1.329227995784916e36f, 5.9604644775390625e-8f));
         }
         *reinterpret_cast<uint4 *>(sB_hi + line * PITCH + 8 * g) = __builtin_bit_cast(uint4, hi);
         *reinterpret_cast<uint4 *>(sB_lo + line * PITCH + 8 * g) = __builtin_bit_cast(uint4, lo);
@@ -123,9 +125,24 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
         constexpr int NIT = (HF_LN * NG + HF_NW * 64 - 1) / (HF_NW * 64);
         hf_f32x4 ld[NIT][2];
         const bool vec = (X & 3) == 0;
+        // (line, group) of unit it * 256 + tid without a division per unit: 256 = 4 NG + 8 for the production radius
+        constexpr int DL = (HF_NW * 64) / NG, DG = (HF_NW * 64) - DL * NG;
+        const int line_0 = tid / NG, g_0 = tid - line_0 * NG;
+        int uline[NIT], ug[NIT];
+        {
+            int line = line_0, g = g_0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                uline[it] = line;
+                ug[it] = g;
+                line += DL;
+                g += DG;
+                if (g >= NG) { g -= NG; ++line; }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int unit = it * (HF_NW * 64) + tid, line = unit / NG, g = unit - line * NG;
+            const int line = uline[it], g = ug[it];
             const float *row = src + (long)min(l0 + min(line, HF_LN - 1), Y - 1) * X;
             const int x0 = p0 - r + 8 * g;
             if (vec && x0 >= 0 && x0 + 8 <= X) {
@@ -138,8 +155,8 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int unit = it * (HF_NW * 64) + tid, line = unit / NG, g = unit - line * NG;
-            if (unit < HF_LN * NG) {
+            const int line = uline[it], g = ug[it];
+            if (line < HF_LN) {
                 const float v[8] = {ld[it][0][0], ld[it][0][1], ld[it][0][2], ld[it][0][3], ld[it][1][0], ld[it][1][1], ld[it][1][2], ld[it][1][3]};
                 split8(v, line, g);
             }
@@ -189,7 +206,7 @@ __global__ void __launch_bounds__(HF_NW * 64, 2) k_corr_long_f16(const float *__
             }
         }
     }
-    if (out_of_range) atomicOr(range_flag, 8);
+    if (!(vmax < 40000.f)) atomicOr(range_flag, 8);               // (never for data bounded by the clip value)
     __syncthreads();
 
     // ---- products ------------------------------------------------------------------------------------------------------------------------
