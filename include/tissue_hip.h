@@ -176,6 +176,9 @@ typedef struct tip_unet_conv_desc {
     float *head_out;            /* Conv2D(128 -> 2, 1x1) weights [2][128], bias [2], softmax -> float32 (2, h, w); `out` unused    */
     int format;                 /* 0: bf16 pieces; 1: fp16 pieces (planes == 2) -- activations, weights and the constants carry the  */
     float acc_scale;            /* caller's power-of-two scales, and the accumulator is multiplied by acc_scale before the bias      */
+    int tf;                     /* != 0: Conv2DTranspose(3, 2, 'same') as ONE launch: ntaps = 4 input offsets (0,0), (0,-1), (-1,0),      */
+    int nmask[9];               /* (-1,-1); `cout`, weights and bias count VIRTUAL channels [cout / 32][class (py, px)][32]; nmask[t] = the */
+                                /* classes tap t feeds (bit py * 2 + px); out = [plane][2h][2w][cout / 4], sy = sx = 2, bias only          */
 } tip_unet_conv_desc;
 TIP_API int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream);
 /* first layer, Conv2D(2 -> 128): float32 (2, h, w) in, weights [9][2][128] float32, exact float32 FMAs               */

@@ -270,6 +270,15 @@ def test_network_hip_path_other_extents(shape, mode, arith, monkeypatch):
     errsep = float((sep.cpu().double() - exp).abs().max())
     dhead = float((sep - fused).abs().max())
     monkeypatch.delenv("TISSUE_HIP_UNET_SEPARATE_HEAD")
+    # the transposed convolution as ONE launch over the four output parity classes (TISSUE_HIP_UNET_TCONV=fused; measured slower, kept
+    # as a selectable variant) instead of the default four: the same accumulation order per output, so the same bits
+    monkeypatch.setenv("TISSUE_HIP_UNET_TCONV", "fused")
+    assert torch.equal(gpu.forward(xg), fused), "one-launch vs four-launch transposed convolution"
+    with _lib.tuning(TIP_UNET_TILE8="1"):
+        one8 = gpu.forward(xg)
+    monkeypatch.delenv("TISSUE_HIP_UNET_TCONV")
+    with _lib.tuning(TIP_UNET_TILE8="1"):
+        assert torch.equal(gpu.forward(xg), one8), "one-launch vs four-launch transposed convolution, 8-row tiles"
     # steps per barrier of the 3x3 16-row kernel (default three) and the workgroup order change the schedule, not the arithmetic
     for knob, val in (("TIP_UNET_SPB", "1"), ("TIP_UNET_SPB", "2"), ("TIP_UNET_XCD_MAP", "0")):
         with _lib.tuning(**{knob: val}):

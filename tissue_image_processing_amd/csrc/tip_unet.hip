@@ -473,6 +473,10 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     p.out = (uint16_t *)d->out; p.outH = d->out_h; p.outW = d->out_w; p.sy = d->sy; p.sx = d->sx; p.oy = d->oy; p.ox = d->ox;
     p.pool_out = (uint16_t *)d->pool_out;
     p.acc_scale = d->format == 1 ? d->acc_scale : 1.f;
+    for (int t = 0; t < 9; ++t) p.nmask[t] = d->tf ? (d->nmask[t] & 15) : 15;
+    if (d->tf && (d->planes != 2 || d->ntaps != 4 || d->sy != 2 || d->sx != 2 || d->oy != 0 || d->ox != 0 || d->scale || d->pool_out || d->head_out ||
+                  d->out_h != 2 * d->h || d->out_w != 2 * d->w))
+        return fail(TIP_ERR_ARG, "tip_unet_conv_dev: the fused transposed convolution takes four offset taps, two planes, bias only, a 2h x 2w output");
 #ifdef UC_TRACE
     static unsigned long long *trace_dev = nullptr;
     if (!trace_dev) { TIP_HIP(hipMalloc(&trace_dev, 1024)); }
@@ -487,6 +491,7 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
         return fail(TIP_ERR_ARG, "tip_unet_conv_dev: pool_out needs the plain output mapping");
     // 16-row tiles (one 512-thread workgroup per CU) where the grid allows: half the weight copies per MFMA, and LDS for five
     // weight buffers (copies four steps ahead) when the stencil has >= 4 taps; two pieces only (LDS)
+    const bool tf = d->tf != 0;
     const int t8 = tuning().unet_tile8;
     // (measured per layer at 2048^2: the short K loops of the 128-channel 3x3 layers gain 1-3 % from two workgroups per CU -- one's
     // epilogue behind the other's products -- every other layer is faster with the shared weight tile of the 16-row workgroup)
@@ -506,10 +511,11 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
     const int spb = !multi ? 1 : (spb_want >= 3 ? 3 : ((((d->c0 + d->c1) / UC_KC) & 1) == 0 ? 2 : 1));
     const size_t lds = (size_t)(da + 1) * a_per * threads * 16 + (size_t)(spb > 1 ? 3 * spb : dist + 1) * d->planes * 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    const int which = d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? (spb == 3 ? 6 : (spb == 2 ? 5 : 2)) : (da == 2 ? 4 : 1)) : 0);
+    const int which = tf ? (th == 16 ? 7 : 8)
+                         : d->planes == 3 ? 3 : (th == 16 ? (dist == 4 ? (spb == 3 ? 6 : (spb == 2 ? 5 : 2)) : (da == 2 ? 4 : 1)) : 0);
     // the >64 KB dynamic LDS attribute is set once per (device, kernel): one atomic bit each
     static std::atomic<unsigned> attr_done[64];
-    const unsigned bit = 1u << (which + (d->format ? 8 : 0));
+    const unsigned bit = 1u << (which + (d->format ? 9 : 0));
     const int dev = c.device >= 0 && c.device < 64 ? c.device : 0;
 #define UC_FLAVOUR(W, ...)                                                                                                                  \
     case W: {                                                                                                                               \
@@ -528,6 +534,8 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
             UC_FLAVOUR(4, k_unet_conv<2, 16, 2, 2>)
             UC_FLAVOUR(1, k_unet_conv<2, 16, 2>)
             UC_FLAVOUR(0, k_unet_conv<2, 8, 2>)
+            UC_FLAVOUR(7, k_unet_conv<2, 16, 4, 1, 1, false, true>)
+            UC_FLAVOUR(8, k_unet_conv<2, 8, 2, 1, 1, false, true>)
         }
     } else {
         switch (which) {
@@ -537,6 +545,8 @@ int tip_unet_conv_dev(const tip_unet_conv_desc *d, void *stream)
             UC_FLAVOUR(4, k_unet_conv<2, 16, 2, 2, 1, true>)
             UC_FLAVOUR(1, k_unet_conv<2, 16, 2, 1, 1, true>)
             UC_FLAVOUR(0, k_unet_conv<2, 8, 2, 1, 1, true>)
+            UC_FLAVOUR(7, k_unet_conv<2, 16, 4, 1, 1, true, true>)
+            UC_FLAVOUR(8, k_unet_conv<2, 8, 2, 1, 1, true, true>)
         }
     }
 #undef UC_FLAVOUR

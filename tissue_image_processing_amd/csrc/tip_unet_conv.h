@@ -66,6 +66,8 @@ struct ConvParams {
 #endif
     int xcd_map;                   // workgroup -> (tile, channel block) mapping, see the kernel
     float acc_scale;               // fp16 pieces: the accumulator is multiplied by this (1 / (activation scale x weight scale), a power of two) before the bias
+    int nmask[9];                  // fused transposed convolution (template TF): which of the four 32-channel accumulator blocks -- the four output
+                                   // parity classes -- tap t feeds (bit n); `cout` then counts VIRTUAL channels [group of 32][class][32]
     uint16_t *pool_out;            // nullptr, or [plane][outH / 2][outW / 2][cout]: MaxPool2D(2) of the output (needs sy = sx = 1)
 };
 
@@ -193,7 +195,12 @@ __device__ __forceinline__ void uc_wait_barrier()
 // may straddle a chunk border (SPB = 2: nine taps per chunk), so the next chunk's activations are issued at the start of the first
 // iteration that BEGINS inside the current chunk: every read of the previous chunk -- whose buffer they overwrite -- lies behind a
 // barrier by then, and at least six steps of flight remain.
-template <int NPL, int TH, int D, int DA = 1, int SPB = 1, bool F16 = false>
+// TF = the stride-2 transposed convolution (pl.py:47) as ONE launch: the four taps are the four input offsets (0, 0), (0, -1), (-1, 0),
+// (-1, -1); the four 32-channel accumulator blocks of a wave are the four output parity classes (py, px) of the SAME 32 output
+// channels, and a tap feeds the classes whose kernel element it holds (nmask: 1111, 0101, 0011, 0001 -- nine products per staged
+// tile instead of 4 / 2 / 2 / 1 in four launches); a workgroup covers 32 real output channels, and the epilogue scatters class n to
+// output pixel (2 y + n / 2, 2 x + n % 2).  Accumulation order per output equals the four-launch form's: bit-identical results.
+template <int NPL, int TH, int D, int DA = 1, int SPB = 1, bool F16 = false, bool TF = false>
 __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer-resource builtins exist in the device pass only; the host pass needs just the stub)
@@ -206,6 +213,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     constexpr int UC_NBBUF = PAIR ? 3 * SPB : D + 1;
     constexpr int UC_THREADS = TH * 32, UC_HP = UC_HW * (TH + 2);
     static_assert(TH == 8 || (TH == 16 && NPL == 2), "16-row tiles: two pieces (LDS)");
+    static_assert(!TF || (NPL == 2 && SPB == 1), "fused transposed convolution: two pieces, one step per barrier");
     // a plane's halo tile is padded to whole waves of slots (A_PLANE): one copy instruction of one wave then serves ONE plane, and
     // the plane picks the buffer resource (scalar) instead of adding a plane stride to the 32-bit per-lane offset
     constexpr int A_GPP = (UC_HP * 2 + 63) / 64, A_PLANE = A_GPP * 64;    // wave-groups / slots per plane (20 / 1280 for 16 rows, 11 / 704 for 8)
@@ -364,7 +372,23 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
         }
         auto read_a = [&](int m, int pl) { fa[m][pl] = *reinterpret_cast<const uint4 *>(abuf + (pl * A_PLANE + aslot[m]) * 16); };
         auto read_b = [&](int n, int pl) { fb[n][pl] = *reinterpret_cast<const uint4 *>(bbuf + (pl * 256 + n * 64 + b_row) * 16); };
-        if constexpr (NPL == 2) {
+        if constexpr (TF) {
+            const int mask = p.nmask[tap];          // (scalar: the classes this input offset feeds)
+            read_a(0, 1); read_a(1, 1); read_a(0, 0); read_a(1, 0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!((mask >> n) & 1)) continue;
+                read_b(n, 0); read_b(n, 1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {       // (the same product order as the general path: lo x hi, hi x lo, hi x hi)
+                    acc[m][n] = uc_mfma<F16>(fb[n][0], fa[m][1], acc[m][n]);
+                    acc[m][n] = uc_mfma<F16>(fb[n][1], fa[m][0], acc[m][n]);
+                    acc[m][n] = uc_mfma<F16>(fb[n][0], fa[m][0], acc[m][n]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (NPL == 2) {
             read_a(0, 1); read_a(1, 1);
 #pragma unroll
             for (int n = 0; n < 4; ++n) read_b(n, 0);
@@ -598,7 +622,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
     }
     auto piece_word = [](float &a, float &b, bool more) -> unsigned { return uc_piece_word<F16>(a, b, more); };
     const int rd_row = lane >> 4, rd_col = (lane & 15) * 16;       // read-back: 16 lanes = one pixel's 256 bytes
-    const long out_plane = (long)p.outH * p.outW * p.cout;
+    const long out_plane = (long)p.outH * p.outW * (TF ? p.cout / 4 : p.cout);
     if (p.pool_out) {
         const long pool_plane = (long)(p.outH / 2) * (p.outW / 2) * p.cout;
         const bool oddp = pxl & 1;
@@ -632,7 +656,12 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int y = ty0 + wave * 2 + m;
-        uint16_t *orow = p.out + ((long)(y * p.sy + p.oy) * p.outW + ((long)tx0 * p.sx + p.ox)) * p.cout + nblk * UC_BN + (lane & 15) * 8;
+        // TF: the 16-byte piece j = lane & 15 of a staged pixel is class j / 4, channels 8 (j % 4) .. of the workgroup's 32: output pixel
+        // (2 y + class / 2, 2 x + class % 2), pixel stride = the real channel count
+        const int cls = (lane & 15) >> 2;
+        const long pix_stride = TF ? p.cout / 4 : p.cout;
+        uint16_t *orow = TF ? p.out + ((long)(2 * y + (cls >> 1)) * p.outW + (2 * (long)tx0 + (cls & 1))) * pix_stride + nblk * 32 + (lane & 3) * 8
+                            : p.out + ((long)(y * p.sy + p.oy) * p.outW + ((long)tx0 * p.sx + p.ox)) * p.cout + nblk * UC_BN + (lane & 15) * 8;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
@@ -656,7 +685,7 @@ __global__ void __launch_bounds__(TH * 32, (NPL == 2) ? 2 : 1) k_unet_conv(const
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + rd_row;
-                *reinterpret_cast<uint4 *>(orow + pl * out_plane + (long)row * p.sx * p.cout) = *reinterpret_cast<const uint4 *>(ep + row * EP_ROW + rd_col);
+                *reinterpret_cast<uint4 *>(orow + pl * out_plane + (long)row * p.sx * pix_stride) = *reinterpret_cast<const uint4 *>(ep + row * EP_ROW + rd_col);
             }
         }
     }

@@ -134,7 +134,7 @@ class _ConvDesc(ctypes.Structure):
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_h", ctypes.c_int),
                 ("out_w", ctypes.c_int), ("sy", ctypes.c_int), ("sx", ctypes.c_int), ("oy", ctypes.c_int), ("ox", ctypes.c_int),
                 ("pool_out", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("head_out", ctypes.c_void_p),
-                ("format", ctypes.c_int), ("acc_scale", ctypes.c_float)]
+                ("format", ctypes.c_int), ("acc_scale", ctypes.c_float), ("tf", ctypes.c_int), ("nmask", ctypes.c_int * 9)]
 
 
 _FILTERS = (128, 256, 512)
@@ -374,12 +374,39 @@ class _UNet(object):
                     wp, inv = pack(taps, True)
                     hw["%s.%d%d" % (name, py, px)] = (wp, [t[1] for t in tl], [t[3] for t in tl], inv)
 
+        def conv_t_fused(name):
+            # the same transposed convolution as ONE launch (csrc/tip_unet_conv.h, template TF): the taps are the four input offsets
+            # (dy, dx) = (0, 0), (0, -1), (-1, 0), (-1, -1); output channels are VIRTUAL, ordered [group of 32][class py * 2 + px][32]:
+            # class (py, px) takes kernel element (ky, kx) = (py ? 1 : (dy ? 2 : 0), px ? 1 : (dx ? 2 : 0)) where its parity has one
+            # at that offset (odd parities only at offset 0), zeros elsewhere -- nmask says which classes a tap feeds
+            w = p[name + ".w"].float()                                  # (cin, cout, 3, 3)
+            cin, cout = int(w.shape[0]), int(w.shape[1])
+            offs = [(0, 0), (0, -1), (-1, 0), (-1, -1)]
+            taps = torch.zeros((4, cin, cout // 32, 4, 32), dtype=torch.float32, device=w.device)
+            masks = []
+            for t, (dy, dx) in enumerate(offs):
+                m = 0
+                for py in (0, 1):
+                    for px in (0, 1):
+                        if (py == 1 and dy != 0) or (px == 1 and dx != 0):
+                            continue
+                        ky = 1 if py else (2 if dy else 0)
+                        kx = 1 if px else (2 if dx else 0)
+                        taps[t, :, :, py * 2 + px, :] = w[:, :, ky, kx].reshape(cin, cout // 32, 32)
+                        m |= 1 << (py * 2 + px)
+                masks.append(m)
+            wp, inv = pack(taps.reshape(4, cin, 4 * cout), True)
+            bias = p[name + ".b"].float().reshape(cout // 32, 1, 32).expand(cout // 32, 4, 32).reshape(-1)
+            hw[name + ".fused"] = (wp, [o[0] for o in offs], [o[1] for o in offs], inv, masks, (bias * act).contiguous())
+
         for blk in ("d0", "d1", "d2", "mid", "u0", "u1", "u2"):
             if blk != "d0":
                 conv3(blk + ".c1")
             conv3(blk + ".c2")
         for i in range(3):
             conv_t("u%d.t" % i)
+            if planes == 2:
+                conv_t_fused("u%d.t" % i)
         w0 = p["d0.c1.w"].float()                                       # (128, 2, 3, 3) -> [tap][ci][cout]
         hw["first"] = w0.permute(2, 3, 1, 0).reshape(18, 128).contiguous()
         hw["head"] = (p["head.w"].float().reshape(2, 128) / act).contiguous()
@@ -428,11 +455,15 @@ class _UNet(object):
         def buf(h, w, c):
             return torch.empty((planes, h, w, c), dtype=torch.float16 if fmt else torch.bfloat16, device=x.device)
 
-        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None):
-            wp, dy, dx, inv = hw[name]
+        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None, fused_t=False):
+            wp, dy, dx, inv = hw[name][:4]
             cout = wp.shape[2] * 128
             d = _ConvDesc()
             d.format, d.acc_scale = fmt, inv
+            if fused_t:
+                d.tf = 1
+                for i, m in enumerate(hw[name][4]):
+                    d.nmask[i] = m
             d.in0, d.c0 = src.data_ptr(), src.shape[3]
             d.in1, d.c1 = (skip.data_ptr(), skip.shape[3]) if skip is not None else (None, 0)
             d.h, d.w, d.planes = h, w, planes
@@ -442,6 +473,8 @@ class _UNet(object):
             d.cout = cout
             if bn is not None:
                 d.bias, d.scale, d.shift = hw["f:" + name + ".b"].data_ptr(), hw["f:" + bn + ".s"].data_ptr(), hw["f:" + bn + ".t"].data_ptr()
+            elif fused_t:
+                d.bias, d.scale, d.shift = hw[name][5].data_ptr(), None, None
             else:
                 d.bias, d.scale, d.shift = hw["f:" + bias + ".b"].data_ptr(), None, None
             if head is not None:                  # the network's head in this layer's epilogue: the layer's own output is not stored
@@ -451,7 +484,8 @@ class _UNet(object):
                 out, oh, ow = buf(h, w, cout), h, w
             d.out, d.out_h, d.out_w, d.sy, d.sx, d.oy, d.ox = (out.data_ptr() if out is not None else None), oh, ow, sy, sx, oy, ox
             d.pool_out = pooled.data_ptr() if pooled is not None else None
-            timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout, len(dy)), 2.0 * h * w * len(dy) * (d.c0 + d.c1) * cout,
+            timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout // 4 if fused_t else cout, 9 if fused_t else len(dy)),
+                  2.0 * h * w * (9 * (cout // 4) if fused_t else len(dy) * cout) * (d.c0 + d.c1),
                   lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream)))
             return out
 
@@ -486,9 +520,16 @@ class _UNet(object):
                 name = "u%d.t" % i
                 cout = hw[name + ".00"][0].shape[2] * 128
                 up = buf(2 * h, 2 * w, cout)
-                for py in (0, 1):
-                    for px in (0, 1):
-                        conv("%s.%d%d" % (name, py, px), cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, oy=py, ox=px, bias=name)
+                if planes == 2 and os.environ.get("TISSUE_HIP_UNET_TCONV", "split") == "fused":
+                    # ONE launch for the four output parity classes (nine products per staged tile; bit-identical).  Measured SLOWER
+                    # than the four launches (6.44 against 6.02 ms over the three layers at 2048^2): a workgroup then covers 32 output
+                    # channels and its four steps per chunk carry 24 / 12 / 12 / 6 MFMAs per wave behind a barrier each, where the
+                    # four-tap class launch carries 24 behind each -- the per-step barrier cost outweighs the shared staging
+                    conv(name + ".fused", cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, fused_t=True)
+                else:
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            conv("%s.%d%d" % (name, py, px), cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, oy=py, ox=px, bias=name)
                 h, w = 2 * h, 2 * w
                 fuse_head = i == 2 and not logits and not os.environ.get("TISSUE_HIP_UNET_SEPARATE_HEAD")
                 if fuse_head:                          # softmax probabilities straight out of the last convolution's epilogue
