@@ -21,7 +21,16 @@ static int ctx_create(int device)
         g_ctx = c;
         return TIP_ERR_HIP;
     }
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    {
+        // TIP_STREAM_PRIORITY=low | high: the library's streams below / above the default priority (an experiment hook: with the
+        // U-Net's convolutions on torch's default-priority streams, "low" lets the short projection / tail kernels fill gaps only)
+        const char *pr = getenv("TIP_STREAM_PRIORITY");
+        int lo = 0, hi = 0;
+        if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && (strcmp(pr, "low") == 0 || strcmp(pr, "high") == 0))
+            e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, strcmp(pr, "low") == 0 ? lo : hi);
+        else
+            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) {
         c->err = std::string("hipStreamCreate failed: ") + hipGetErrorString(e);
         c->stream = nullptr;
