@@ -201,6 +201,18 @@ TIP_API int tip_unet_prepare_f64_dev(const double *img, int c, int a, int b, lon
 TIP_API int tip_unet_tail_dev(const void *p, int dtype, long ld, int y, int x, double thr, int32_t *labels, double *hc,
                               int32_t *flags_host);
 
+/* ---- overlay images of Tissue.draw_* (ti.py:584-607, 2585-2645): (3, y, x) float64 images the GUI composites over a frame.   */
+/* Host arrays in and out.  cell types: positive = all bits of must_mask set (and the byte != 255 unless must_mask is 0) and   */
+/* no bit of lack_mask set on a valid byte (is_positive_for_type, ti.py:146-176); negative = valid and not positive.          */
+/* tracking: colour cycle18[id % 6], id 0 black (ti.py:2625-2635).  disks: skimage.draw.disk(center, radius, shape), a later    */
+/* disc paints over an earlier one (draw_events / draw_cell_tracking / draw_marking_points).  lines: skimage.draw.line          */
+/* between (r0, c0, r1, c1) quadruples (draw_neighbors_connections).                                                            */
+TIP_API int tip_draw_cell_types_u8(const uint8_t *types, long n, int must_mask, int lack_mask, const double *pos_rgb,
+                                   const double *neg_rgb, double *out3);
+TIP_API int tip_draw_tracking_i32(const int32_t *track, long n, const double *cycle18, double *out3);
+TIP_API int tip_draw_disks_f64(int y, int x, int n, const double *cy, const double *cx, double radius, const double *rgb, double *out3);
+TIP_API int tip_draw_lines_f64(int y, int x, int n, const int32_t *ends, const double *rgb, double *out3);
+
 /* ---- rank filters ---------------------------------------------------------------------------- */
 /* scipy.ndimage.maximum_filter / minimum_filter (ti.py:1822,2081,2969,4079-4084) and             */
 /* skimage.morphology.erosion/dilation with a flat footprint (pl.py:170-193).                     */

@@ -729,3 +729,84 @@ def update_drift(previous_img, current_img):
     """Tissue.update_drift without stage locations (ti.py:1982-2035): returns (shift_y, shift_x) = (refined[-1], refined[-2])."""
     r = phase_cross_correlation(previous_img, current_img, upsample_factor=100)
     return r[-1], r[-2]
+
+
+# ---- overlays (ti.py:584-607, 2585-2645) ------------------------------------------------------------------------------------------
+def disk_mask(shape, center, radius):
+    """skimage.draw.disk(center, radius, shape=shape) as a boolean image (skimage/draw/draw.py: ellipse / _ellipse_in_shape: the
+    pixels of the box ceil(center - r) .. floor(center + r), clipped to the image, with ((r - r0) / R)^2 + ((c - c0) / R)^2 < 1,
+    coordinates relative to the box)."""
+    Y, X = int(shape[0]), int(shape[1])
+    r0, c0 = float(center[0]), float(center[1])
+    ur, uc = max(int(np.ceil(r0 - radius)), 0), max(int(np.ceil(c0 - radius)), 0)
+    lr, lc = min(int(np.floor(r0 + radius)), Y - 1), min(int(np.floor(c0 + radius)), X - 1)
+    out = np.zeros((Y, X), bool)
+    if lr < ur or lc < uc:
+        return out
+    rr = np.arange(0, lr - ur + 1, dtype=np.float64)[:, None] - (r0 - ur)
+    cc = np.arange(0, lc - uc + 1, dtype=np.float64)[None, :] - (c0 - uc)
+    out[ur:lr + 1, uc:lc + 1] = (rr / radius) ** 2 + ((-cc) / radius) ** 2 < 1
+    return out
+
+
+def draw_disks(shape, centers, radius, colors):
+    """(3, Y, X) float64: discs painted in order, a later one over an earlier one"""
+    out = np.zeros((3,) + tuple(shape), np.float64)
+    for (cy, cx), col in zip(centers, colors):
+        m = disk_mask(shape, (cy, cx), radius)
+        for j in range(3):
+            out[j][m] = col[j]
+    return out
+
+
+def line_pixels(r0, c0, r1, c1):
+    """skimage.draw.line (skimage/draw/_draw.pyx `_line`, a binary in the container: the published integer Bresenham walk)"""
+    r, c = int(r0), int(c0)
+    dr, dc = abs(int(r1) - r), abs(int(c1) - c)
+    sc = 1 if (int(c1) - c) > 0 else -1
+    sr = 1 if (int(r1) - r) > 0 else -1
+    steep = dr > dc
+    if steep:
+        c, r = r, c
+        dc, dr = dr, dc
+        sc, sr = sr, sc
+    d = 2 * dr - dc
+    pix = []
+    for _ in range(dc):
+        pix.append((c, r) if steep else (r, c))
+        while d >= 0:
+            r += sr
+            d -= 2 * dc
+        c += sc
+        d += 2 * dr
+    pix.append((int(r1), int(c1)))
+    return pix
+
+
+def draw_lines(shape, ends, color):
+    img = np.zeros(tuple(shape), np.float64)
+    for r0, c0, r1, c1 in ends:
+        for r, c in line_pixels(r0, c0, r1, c1):
+            img[r, c] = 1
+    return np.tile(img, (3, 1, 1)) * np.asarray(color, np.float64).reshape(3, 1, 1)
+
+
+def draw_cell_types(cell_types, type_index, pos_color=(1, 0, 1), neg_color=(1, 1, 0)):
+    """ti.py:2585-2593 with is_positive_for_type's bit test (ti.py:164-176): scalar type index"""
+    t = np.asarray(cell_types).astype(np.uint8)
+    bit = np.uint8(1 << type_index)
+    pos = ((t & bit) == bit) & (t != 255)
+    neg = ~pos & (t != 255)
+    return pos * np.asarray(pos_color, np.float64).reshape(3, 1, 1) + neg * np.asarray(neg_color, np.float64).reshape(3, 1, 1)
+
+
+def draw_tracking(track, cycle=((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1))):
+    """ti.py:2625-2635"""
+    track = np.asarray(track)
+    out = np.zeros((3,) + track.shape, np.float64)
+    for i in range(len(cycle)):
+        for j in range(3):
+            out[j][track % len(cycle) == i] = cycle[i][j]
+    for j in range(3):
+        out[j][track == 0] = 0
+    return out

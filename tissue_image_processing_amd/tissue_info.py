@@ -26,6 +26,15 @@ CELL_INFO_SPECS = {"area": 0, "perimeter": 0, "label": 0, "cx": 0, "cy": 0, "nei
                    "valid": 0, "type": 0, "bounding_box_min_row": 0, "bounding_box_min_col": 0,
                    "bounding_box_max_row": 0, "bounding_box_max_col": 0, "empty_cell": 0}
 INVALID_TYPE_INDEX = 255
+# overlay colours (ti.py:68-77)
+TRACK_COLOR = (0, 1, 0)
+NEIGHBORS_COLOR = (1, 1, 1)
+POS_COLOR = (1, 0, 1)
+NEG_COLOR = (1, 1, 0)
+MARKING_COLOR = (0.5, 0.5, 0.5)
+EVENTS_COLOR = {"ablation": (1, 1, 0), "division": (0, 0, 1), "delamination": (1, 0, 0), "differentiation": (0, 1, 1),
+                "promoted differentiation": (1, 1, 1)}
+TRACKING_COLOR_CYCLE = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)]
 
 
 def make_df(number_of_lines, specs):
@@ -665,6 +674,348 @@ class TissueHipMixin(object):
         _lib.check(_lib.lib().tip_lut_gather_i32(_lib.ptr(lab32), _lib.ptr(cell_ids), ctypes.c_int64(cell_ids.size),
                                                  _lib.ptr(out), ctypes.c_int64(lab32.size)))
         return out
+
+
+    # ---- overlays (ti.py:584-607, 2585-2645) and event detection (ti.py:609-789) ---------------------------
+    def type_name_to_index(self, type_name):
+        """ti.py:366-372 (names only; the "pos / neg" list form goes through type_pos_neg_list_to_indices when the host class has it)."""
+        names = list(getattr(self, "type_names", []))
+        if type_name in names:
+            return names.index(type_name)
+        if ("pos" in type_name or "neg" in type_name) and hasattr(self, "type_pos_neg_list_to_indices"):
+            return self.type_pos_neg_list_to_indices(type_name)
+        return -1
+
+    def get_cell_data_by_label(self, cell_id, frame):
+        """ti.py:911-919: the valid, non-empty rows of the frame's table whose track id is cell_id (None when there is none)."""
+        table = self.get_cells_info(frame)
+        if table is None:
+            return None
+        rows = table.query("label == %d and valid == 1 and empty_cell == 0" % cell_id)
+        return rows if rows.shape[0] > 0 else None
+
+    @staticmethod
+    def _disks_image(shape, centers, radius, colors):
+        """(3, Y, X) float64: filled discs (skimage.draw.disk), later ones over earlier ones -- on the device"""
+        Y, X = int(shape[0]), int(shape[1])
+        cy = np.ascontiguousarray([c[0] for c in centers], dtype=np.float64)
+        cx = np.ascontiguousarray([c[1] for c in centers], dtype=np.float64)
+        rgb = np.ascontiguousarray(colors, dtype=np.float64).reshape(-1)
+        out = np.empty((3, Y, X), np.float64)
+        _lib.check(_lib.lib().tip_draw_disks_f64(Y, X, int(cy.size), _lib.ptr(cy), _lib.ptr(cx), ctypes.c_double(float(radius)),
+                                                 _lib.ptr(rgb), _lib.ptr(out)))
+        return out
+
+    def draw_cell_types(self, frame_number, type_name=""):
+        """ti.py:2585-2593: positive cells in POS_COLOR, the other valid cells in NEG_COLOR."""
+        type_index = self.type_name_to_index(type_name)
+        cell_types = self.get_cell_types(frame_number)
+        if (not isinstance(type_index, tuple) and type_index < 0) or cell_types is None:
+            return 0
+        if isinstance(type_index, tuple):
+            must = sum(1 << int(t) for t in set(type_index[0]))
+            lack = sum(1 << int(t) for t in set(type_index[1]))
+        else:
+            must, lack = 1 << int(type_index), 0
+        types = np.ascontiguousarray(np.asarray(cell_types).astype(np.uint8))
+        out = np.empty((3,) + types.shape, np.float64)
+        pos, neg = np.asarray(POS_COLOR, np.float64), np.asarray(NEG_COLOR, np.float64)
+        _lib.check(_lib.lib().tip_draw_cell_types_u8(_lib.ptr(types), ctypes.c_long(types.size), must, lack, _lib.ptr(pos), _lib.ptr(neg),
+                                                     _lib.ptr(out)))
+        return out
+
+    def draw_neighbors_connections(self, frame_number):
+        """ti.py:2595-2606: a line between the (truncated) centroids of every cell and each of its neighbours."""
+        labels = self.get_labels(frame_number)
+        table = self.get_cells_info(frame_number)
+        if labels is None or table is None:
+            return np.zeros(np.shape(labels) if labels is not None else (0, 0))
+        cy, cx = table.cy.to_numpy(), table.cx.to_numpy()
+        ends = []
+        for row, neigh in enumerate(table.neighbors):
+            for nl in list(neigh):
+                ends.append((int(cy[row]), int(cx[row]), int(cy[nl - 1]), int(cx[nl - 1])))
+        ends = np.ascontiguousarray(ends, dtype=np.int32).reshape(-1, 4)
+        Y, X = labels.shape
+        out = np.empty((3, Y, X), np.float64)
+        rgb = np.asarray(NEIGHBORS_COLOR, np.float64)
+        _lib.check(_lib.lib().tip_draw_lines_f64(int(Y), int(X), int(ends.shape[0]), _lib.ptr(ends), _lib.ptr(rgb), _lib.ptr(out)))
+        return out
+
+    def draw_cell_tracking(self, frame_number, cell_label, radius=5):
+        """ti.py:2608-2623: a disc on the tracked cell (all tracks in their cycle colours for label 0); a cell that is not in the
+        frame gives upstream's plain 2-D zero image."""
+        if cell_label == 0:
+            return self.draw_all_cell_tracking(frame_number)
+        labels = self.get_labels(frame_number)
+        if labels is None:
+            return 0
+        cell = self.get_cell_data_by_label(cell_label, frame_number)
+        if cell is None or cell.empty_cell.values[0] == 1:
+            return np.zeros(labels.shape)
+        return self._disks_image(labels.shape, [(cell.cy.values[0], cell.cx.values[0])], radius, [TRACK_COLOR])
+
+    def draw_all_cell_tracking(self, frame):
+        """ti.py:2625-2635: every pixel in the colour of its track id modulo six, background black."""
+        track = np.ascontiguousarray(self.get_trackking_labels(frame), dtype=np.int32)
+        out = np.empty((3,) + track.shape, np.float64)
+        cyc = np.ascontiguousarray(TRACKING_COLOR_CYCLE, dtype=np.float64).reshape(-1)
+        _lib.check(_lib.lib().tip_draw_tracking_i32(_lib.ptr(track), ctypes.c_long(track.size), _lib.ptr(cyc), _lib.ptr(out)))
+        return out
+
+    def draw_marking_points(self, frame_number, radius=5):
+        """ti.py:2637-2645: discs on the shape-fitting points ((x, y) pairs)."""
+        labels = self.get_labels(frame_number)
+        pts = list(getattr(self, "shape_fitting_points", None) or [])
+        return self._disks_image(labels.shape, [(p[1], p[0]) for p in pts], radius, [MARKING_COLOR] * len(pts))
+
+    def draw_events(self, frame, radius=5):
+        """ti.py:584-607: a disc in the event's colour on every cell with an event spanning the frame (and on a division's daughter)."""
+        labels = self.get_labels(frame)
+        if labels is None:
+            return 0
+        centers, colors = [], []
+        for _, event in self.events.iterrows():
+            if not (event.start_frame <= frame <= event.end_frame):
+                continue
+            cell = self.get_cell_data_by_label(event.cell_id, frame)
+            if cell is None or cell.empty_cell.values[0] == 1:
+                continue
+            color = EVENTS_COLOR[event.type]
+            centers.append((cell.cy.values[0], cell.cx.values[0]))
+            colors.append(color)
+            if event.type == "division":
+                other = self.get_cell_data_by_label(event.daughter_id, frame)
+                if other is not None and other.empty_cell.values[0] == 0:
+                    centers.append((other.cy.values[0], other.cx.values[0]))
+                    colors.append(color)
+        return self._disks_image(labels.shape, centers, radius, colors)
+
+    # -- the events table (ti.py:500-582, 998-1033): what find_events_iterator reports into ---------------------------------------
+    def is_frame_valid(self, frame):
+        return self.valid_frames[frame - 1] == 1
+
+    def find_event_frame(self, event):
+        """ti.py:998-1033, as written: the frame an event is pinned to.  (A delamination is pinned to the frame before the first
+        valid one in which its cell is present and non-empty -- or whose area has fallen below min_cell_area --; a division to the
+        frame before the daughter first shows; a differentiation's test compares the numeric type with the string "HC", so it ends
+        at upstream's fall-through: the start frame.)"""
+        first, last, kind = event["start_frame"], event["end_frame"], event["type"]
+        if kind == "delamination":
+            seen = first
+            for frame in range(first, last + 1):
+                if self.is_frame_valid(frame):
+                    cell = self.get_cell_data_by_label(event["cell_id"], frame)
+                    if cell is None or cell.empty_cell.values[0] == 0:
+                        return seen
+                    elif float(cell.area.values[0]) < self.min_cell_area:
+                        return frame
+                    seen = frame
+        if kind == "division":
+            seen = first
+            for frame in range(first, last + 1):
+                if self.is_frame_valid(frame):
+                    cell = self.get_cell_data_by_label(event["daughter_id"], frame)
+                    if cell is not None and cell.empty_cell.values[0] == 0:
+                        return seen
+                    seen = frame
+        if kind == "differentiation":
+            seen = first
+            for frame in range(first, last + 1):
+                if self.is_frame_valid(frame):
+                    cell = self.get_cell_data_by_label(event["cell_id"], frame)
+                    if cell is not None and cell.type.values[0] == "HC":
+                        return seen
+                    seen = frame
+        print("Problem with finding event frame")
+        return first
+
+    def delete_event(self, start_frame, start_pos):
+        cell_id = self.get_cell_id_by_position(start_frame, start_pos)
+        hit = self.events.query("start_frame == %d and (cell_id == %d or daughter_id == %d)" % (start_frame, cell_id, cell_id))
+        if hit.size > 0:
+            self.events.drop(hit.index, inplace=True)
+        return 0
+
+    def add_event(self, event_type, start_frame, end_frame, start_pos=None, end_pos=None, second_end_pos=None, start_cell_id=None,
+                  daughter_cell_id=None, source="manual"):
+        """ti.py:500-560: a row of the events table -- cell ids from clicked positions or positions from the cells' centroids (the end
+        position walks back from end_frame to the last frame that still has the cell; upstream's loop also gives up when that walk
+        would pass start_frame on its NEXT step, found or not -- kept), the daughter's data for divisions, the pinned frame."""
+        if start_frame is None:
+            return 0
+        if event_type == "delete event":
+            self.delete_event(start_frame, start_pos)
+            return 0
+        if start_pos is not None:
+            start_cell_id = self.get_cell_id_by_position(start_frame, start_pos)
+        else:
+            start_pos = self.get_cell_centroid_by_id(start_frame, start_cell_id)
+            if start_pos is None:
+                return 0
+        if end_pos is not None:
+            end_cell_id = self.get_cell_id_by_position(end_frame, end_pos)
+        else:
+            end_cell_id = start_cell_id
+            back = 0
+            while end_pos is None:
+                end_pos = self.get_cell_centroid_by_id(end_frame - back, start_cell_id)
+                back += 1
+                if end_frame - back < start_frame:
+                    return 0
+        if start_cell_id != end_cell_id and event_type == "differentiation":
+            self.fix_cell_label(end_frame, end_pos, start_cell_id)         # (manual-editing code of the host class, ti.py:3029-)
+        row = {"type": event_type, "start_frame": start_frame, "end_frame": end_frame, "start_pos_x": start_pos[0],
+               "start_pos_y": start_pos[1], "end_pos_x": end_pos[0], "end_pos_y": end_pos[1], "daughter_pos_x": 0, "daughter_pos_y": 0,
+               "cell_id": start_cell_id, "daughter_id": 0, "source": source}
+        if second_end_pos is not None or daughter_cell_id is not None:
+            second_id = self.get_cell_id_by_position(end_frame, second_end_pos) if daughter_cell_id is None else daughter_cell_id
+            if second_end_pos is None:
+                second_end_pos = self.get_cell_centroid_by_id(end_frame, daughter_cell_id)
+                if second_id is None:
+                    return 0
+            if start_cell_id != end_cell_id and start_cell_id == second_id:
+                second_id = end_cell_id
+            row["daughter_pos_x"], row["daughter_pos_y"], row["daughter_id"] = second_end_pos[0], second_end_pos[1], second_id
+        row["significant_frame"] = int(self.find_event_frame(row))
+        self.events = pd.concat([self.events, pd.DataFrame(row, index=[0])], ignore_index=True)
+        return 0
+
+    @staticmethod
+    def detect_edge_cells(labels):
+        """ti.py:609-612: row indices (label - 1) of the cells that touch the frame's border."""
+        border = np.hstack([labels[0, :], labels[:, 0], labels[-1, :], labels[:, -1]])
+        return np.unique(border[border > 0]) - 1
+
+    def find_valid_frames(self, initial_frame, final_frame):
+        """ti.py:621-626 (the upper end is exclusive, as upstream's arange)."""
+        first, last = max(1, initial_frame), min(self.number_of_frames, final_frame)
+        idx = np.arange(first, last) - 1
+        return idx[np.asarray(self.valid_frames)[idx] == 1] + 1
+
+    def find_events(self, initial_frame, final_frame):
+        last = initial_frame
+        for frame in self.find_events_iterator(initial_frame, final_frame):
+            last = frame
+        return last
+
+    def find_events_iterator(self, initial_frame=1, final_frame=-1, differentiation_type_name="", differentiation_type_index=0):
+        """ti.py:636-789: delaminations (a valid interior cell that is gone in the next valid frame while all its neighbours stay),
+        differentiations (a cell that turns positive for the type while its neighbourhood stays) and divisions (a new interior cell
+        whose centroid and a staying neighbour's centroid fall into ONE cell of the previous frame's label map), reported through
+        self.add_event.  Upstream's quirks are part of the behaviour and kept: a neighbour LABEL is looked up as a ROW of the valid
+        cells' table (no minus one), the border cells are those of the first frame throughout, drifts are truncated before they are
+        added, and a division's end frame walks back to the daughter's last valid frame."""
+        if differentiation_type_name:
+            index = self.type_name_to_index(differentiation_type_name)
+            if isinstance(index, tuple) or index >= 0:
+                differentiation_type_index = index
+        if final_frame == -1:
+            final_frame = self.number_of_frames
+        labels = table = None
+        initial_frame -= 1
+        while labels is None or table is None:
+            initial_frame += 1
+            labels, table = self.get_labels(initial_frame), self.get_cells_info(initial_frame)
+
+        def valid_rows(tab):
+            return tab.query("valid == 1 and empty_cell == 0")
+
+        def positives(rows):
+            return rows.loc[is_positive_for_type(rows.type.to_numpy(), differentiation_type_index)].label
+
+        prev_rows = valid_rows(table)
+        prev_ids, prev_pos = prev_rows.label, positives(prev_rows)
+        prev_labels = np.copy(labels)
+        first_edge_ids = table.label[self.detect_edge_cells(labels)]
+        skipped = 0
+
+        def neighbourhood_stays(rows, cell_id, ids, blocked, frame):
+            """every neighbour label, read as a row of `ids`, is a cell that neither vanished nor sits on the border; None: no such cell"""
+            neigh = rows.query("label == %d" % cell_id).neighbors
+            if neigh.shape[0] < 1:
+                return None
+            if neigh.shape[0] > 1:
+                print("Warning: more than one cell with the same id. frame: %d, cell id: %d" % (frame, cell_id))
+            for n in list(neigh.values[0]):
+                if n not in ids:                       # (membership in the Series' INDEX, as upstream)
+                    return False
+                if blocked(ids[n]):
+                    return False
+            return True
+
+        for frame in range(initial_frame + 1, final_frame + 1):
+            if not self.valid_frames[frame - 1]:
+                skipped += 1
+                continue
+            around = self.find_valid_frames(frame - 5, frame + 5)
+            start_frame, end_frame = np.min(around), np.max(around)
+            labels, table = self.get_labels(frame), self.get_cells_info(frame)
+            cur_rows = valid_rows(table)
+            cur_ids, cur_pos = cur_rows.label, positives(cur_rows)
+            cur_edge_ids = table.label[self.detect_edge_cells(labels)]
+            if skipped < 3:
+                gone = np.setdiff1d(prev_ids.values, cur_ids.values)
+                blocked_prev = lambda i: i in gone or i in first_edge_ids.values      # noqa: E731
+                for cid in gone:                                                    # delaminations
+                    if cid in first_edge_ids.values:
+                        continue
+                    if neighbourhood_stays(prev_rows, cid, prev_ids, blocked_prev, frame):
+                        self.add_event("delamination", start_frame, frame, start_cell_id=cid, source="automatic")
+                both = np.intersect1d(cur_ids.values, prev_ids.values)
+                for cid in np.intersect1d(np.setdiff1d(cur_pos.values, prev_pos.values), both):      # differentiations
+                    if neighbourhood_stays(prev_rows, cid, prev_ids, blocked_prev, frame):
+                        self.add_event("differentiation", start_frame, end_frame, start_cell_id=cid, source="automatic")
+                for cid in np.setdiff1d(cur_ids.values, prev_ids.values):            # divisions
+                    if cid in cur_edge_ids.values:
+                        continue
+
+                    def previous_label_under(cell):
+                        """label of the previous frame's map under the cell's (drift-shifted) rounded centroid; None outside the frame"""
+                        cen = self.get_cell_centroid_by_id(frame, cell)
+                        px, py = int(np.round(cen[0])), int(np.round(cen[1]))
+                        if self.drifts is not None:
+                            drift = self.drifts[frame - 1, :]
+                            if drift[0] != np.nan:
+                                px += int(drift[1])
+                                py += int(drift[0])
+                        if px < 0 or px >= prev_labels.shape[1] or py < 0 or py >= prev_labels.shape[0]:
+                            return None
+                        return prev_labels[py, px]
+
+                    mother_label = previous_label_under(cid)
+                    if mother_label is None:
+                        continue
+                    neigh = cur_rows.query("label == %d" % cid).neighbors
+                    if neigh.shape[0] < 1:
+                        continue
+                    if neigh.shape[0] > 1:
+                        print("Warning: more than one cell with the same id. frame: %d, cell id: %d" % (frame, cid))
+                    found, mother_id, daughter_pos, division_end = False, None, None, end_frame
+                    for n in list(neigh.values[0]):
+                        if n not in cur_ids:
+                            found = False
+                            break
+                        nid = cur_ids[n]
+                        if nid in both and nid not in cur_edge_ids.values:
+                            under = previous_label_under(nid)
+                            if under is None:
+                                continue
+                            if under == mother_label:
+                                division_end, daughter_pos = end_frame + 1, None
+                                while daughter_pos is None:
+                                    division_end -= 1
+                                    if self.valid_frames[division_end - 1] == 1:
+                                        daughter_pos = self.get_cell_centroid_by_id(division_end, cid)
+                                found, mother_id = True, nid
+                    if found:
+                        self.add_event("division", start_frame, division_end, start_cell_id=mother_id, daughter_cell_id=cid,
+                                       second_end_pos=daughter_pos, source="automatic")
+            prev_rows, prev_ids, prev_pos = cur_rows, cur_ids, cur_pos
+            prev_labels = np.copy(labels)
+            skipped = 0
+            yield frame
+        return 0
 
 
 EVENTS_INFO_SPEC = {"type": "TBA", "start_frame": 0, "end_frame": 0, "start_pos_x": 0, "start_pos_y": 0, "end_pos_x": 0,
