@@ -67,6 +67,8 @@ TIP_API int tip_sync(void);                       /* wait for this thread's stre
 /*   TIP_UNET_TAIL_UNFUSED                                                            tail morphology as separate launches */
 /* None of them changes results: they select between schedules / kernels that are tested to agree bit for bit       */
 /* (TIP_WS_TIES = fast is the one exception and says so in `flags`).                                                */
+/* Quiescent use only: entry points read the table without a lock (aligned ints: never torn, but a call in flight   */
+/* while a hook changes may run partly under each value). Set hooks while no other thread is inside the library.    */
 TIP_API int tip_set_tuning(const char *name, const char *value);
 
 /* per-kernel timing with HIP events on the library's own stream (bench.py roofline leg) */

@@ -410,6 +410,9 @@ int tip_prof_report(char *buf, size_t n)
 
 // name: one of the TIP_* tuning names (include/tissue_hip.h); value: its textual form, NULL or "" for the default.
 // The table is read from the environment once, when the library first needs it; afterwards this is the only way in.
+// QUIESCENT USE ONLY: the entry points read the table's plain ints without a lock (one aligned int each: a reader sees the old or the
+// new value of a hook, never a torn one, but a call that is in flight while a hook changes may run partly under each) -- the hooks are
+// test / experiment switches; set them while no other thread is inside the library.
 int tip_set_tuning(const char *name, const char *value)
 {
     (void)tuning();
