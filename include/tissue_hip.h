@@ -65,6 +65,8 @@ TIP_API int tip_sync(void);                       /* wait for this thread's stre
 /*   TIP_PROJECT_DEBUG, TIP_FAST_CFG = y,x, TIP_MFMA_BLOCKS_PER_CU                     projection kernel selection   */
 /*   TIP_UNET_TILE8 = -1|0|1, TIP_UNET_SPB = 1|2|3, TIP_UNET_XCD_MAP = 0|1             U-Net convolution schedule    */
 /*   TIP_UNET_TAIL_UNFUSED                                                            tail morphology as separate launches */
+/*   TIP_MB_SMALL = pixels, TIP_MB_BATCH = generations                                 two-valued flood: one-workgroup  */
+/*                                                                                    generations / host looks         */
 /* None of them changes results: they select between schedules / kernels that are tested to agree bit for bit       */
 /* (TIP_WS_TIES = fast is the one exception and says so in `flags`).                                                */
 /* Quiescent use only: entry points read the table without a lock (aligned ints: never torn, but a call in flight   */

@@ -188,6 +188,32 @@ def test_watershed_binary_degenerate_shapes(env):
         assert mism == 0, "case %d: %d mismatches" % (k, mism)
 
 
+@pytest.mark.parametrize("small,batch", [("0", "8"), ("1", "1"), ("48", "2"), ("700", "3"), ("32768", "4")])
+def test_watershed_binary_small_generation_kernel(env, small, batch):
+    """The two-valued flood's late generations run in ONE workgroup (k_mb_small_gens) as soon as a generation has at most
+    TIP_MB_SMALL pixels, and go back to the grid-wide kernels when a generation grows past it again.  Every threshold (0 = never)
+    and every batching of the host's looks at the device state gives the oracle's labels: generations that shrink (boundary
+    bands), grow (three small markers flooding a plateau: the front widens for a hundred generations) and do both."""
+    _, seg, _, orc = env
+    from tissue_image_processing_amd import _lib
+    rng = np.random.default_rng(21)
+    imgs = [boundary_image(384, 2)]
+    a = np.full((150, 190), 255.0)
+    a[5:9, 5:9] = 0; a[100:104, 130:140] = 0; a[60, 70] = 0
+    imgs.append(a)
+    b = np.full((200, 200), 255.0)                                      # a plateau behind a one-pixel gate: small, large, small again
+    b[:, 60] = 0; b[100, 60] = 255.0; b[:, :3] = 0; b[20:24, 150:154] = 0
+    imgs.append(b)
+    imgs.append((rng.random((90, 110)) > 0.35) * 255.0)
+    refs = [orc.watershed(im) for im in imgs]
+    with _lib.tuning(TIP_MB_SMALL=small, TIP_MB_BATCH=batch):
+        for k, (im, ref) in enumerate(zip(imgs, refs)):
+            out, flags = seg.watershed(np.ascontiguousarray(im, np.float64), return_flags=True)
+            assert flags & 2, k
+            mism = int((out != ref).sum())
+            assert mism == 0, "case %d (small %s, batch %s): %d mismatches" % (k, small, batch, mism)
+
+
 def _uint16_frame_and_reference(orc, N, seed=44):
     """A uint16-normalised projection (save_tiff's normalisation, bim.py:183-188) and the oracle's restatement of what
     bim.py:446-476 does to it: threshold, scipy's integer-dtype blur (truncation after every axis), serial flood."""

@@ -176,6 +176,8 @@ bool tuning_assign(Tuning &t, const char *name, const char *value)
     else if (n == "TIP_UNET_SPB") num(t.unet_spb, def.unet_spb);
     else if (n == "TIP_UNET_XCD_MAP") flag(t.unet_xcd_map, 1);
     else if (n == "TIP_UNET_TAIL_UNFUSED") flag(t.unet_tail_unfused, 0);
+    else if (n == "TIP_MB_SMALL") num(t.mb_small, def.mb_small);
+    else if (n == "TIP_MB_BATCH") num(t.mb_batch, def.mb_batch);
     else return false;
     return true;
 }
@@ -183,7 +185,7 @@ bool tuning_assign(Tuning &t, const char *name, const char *value)
 const char *const TUNING_NAMES[] = {"TIP_WS_TIES", "TIP_WS_TILE", "TIP_WS_OPEN", "TIP_WS_CERT_FROM", "TIP_WS_NO_SKIP", "TIP_WS_LDS_PAD",
                                     "TIP_WS_DEBUG", "TIP_WS_NO_ENDGAME", "TIP_WS_NO_WIDE", "TIP_MFMA_BLOCKS_PER_CU", "TIP_PROJECT_GENERIC",
                                     "TIP_PROJECT_UNFUSED_PREBLUR", "TIP_PROJECT_UNFUSED_MASK", "TIP_PROJECT_EXACT_SCORE", "TIP_PROJECT_DEBUG",
-                                    "TIP_FAST_CFG", "TIP_UNET_TILE8", "TIP_UNET_TAIL_UNFUSED", "TIP_UNET_XCD_MAP", "TIP_UNET_SPB", "TIP_UF_ONE_LEVEL"};
+                                    "TIP_FAST_CFG", "TIP_UNET_TILE8", "TIP_UNET_TAIL_UNFUSED", "TIP_UNET_XCD_MAP", "TIP_UNET_SPB", "TIP_UF_ONE_LEVEL", "TIP_MB_SMALL", "TIP_MB_BATCH"};
 
 void tuning_from_env()
 {

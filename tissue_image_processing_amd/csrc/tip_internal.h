@@ -71,6 +71,8 @@ struct Tuning {
     int unet_xcd_map = 1;       // TIP_UNET_XCD_MAP: the channel blocks of one pixel tile side by side on one XCD (0: all workgroups in flight on one channel block)
     int unet_spb = 3;           // TIP_UNET_SPB: steps per barrier of the 3x3 16-row convolution kernel (1, 2 or 3)
     int uf_one_level = 0;       // TIP_UF_ONE_LEVEL: the one-level union-find (global atomics only) instead of tiles in LDS + borders (tests)
+    int mb_small = -1;          // TIP_MB_SMALL: generations of the two-valued flood of at most this many pixels run in one workgroup (0: never; -1: the built-in default)
+    int mb_batch = -1;          // TIP_MB_BATCH: generations queued between two looks at the device state (-1: the built-in default)
     int unet_tile8 = -1;        // TIP_UNET_TILE8: the U-Net convolution's tile rows: 1 = 8 everywhere, 0 = 16 where the grid allows, -1 (default) = 16 except for 3x3 layers with <= 128 input channels
 };
 const Tuning &tuning();

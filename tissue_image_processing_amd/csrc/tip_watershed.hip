@@ -936,46 +936,23 @@ __global__ void __launch_bounds__(256) k_mb_push_markers(unsigned long long *__r
     bl_flush(bl, next, counter);
 }
 
-__global__ void __launch_bounds__(256) k_mb_push_list(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
-                                                      const int *__restrict__ list, int nlist, int *__restrict__ next,
-                                                      int *__restrict__ counter, int Y, int X)
-{
-    __shared__ int s_items[4 * 256], s_count, s_base;
-    const BlockList bl{s_items, &s_count, &s_base};
-    bl_init(bl);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nlist) mb_push_from(st, cand, bl, list[i], Y, X);
-    bl_flush(bl, next, counter);
-}
-
-__global__ void __launch_bounds__(256) k_mb_flag_keys(const unsigned long long *__restrict__ cand, const int *__restrict__ next,
-                                                      int nnext, int *__restrict__ flag)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnext) flag[(unsigned)(cand[next[i]] >> 32)] = 1;
-}
-
-__global__ void __launch_bounds__(256) k_mb_assign_ranks(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                         const int *__restrict__ next, int nnext, const int *__restrict__ drank,
-                                                         int *__restrict__ list)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nnext) return;
-    const int u = next[i];
-    const int r = drank[(unsigned)(cand[u] >> 32)];
-    st[u] = pack_st(0, r + 1);
-    list[r] = u;
-}
-
 // fate of one pixel of the generation (rank r): true when decided.  When the pixel pops, the neighbours labelled before it
 // are those of earlier generations plus the same-generation neighbours of smaller rank that took a label.  A pending
 // same-generation neighbour q of smaller rank will end as a line (ignored) or with its pusher's label, which is already
 // known (cand[q]): if that label equals the one label this pixel sees, q cannot change the outcome and is not waited for --
 // a pixel only waits for smaller-ranked neighbours that would bring a DIFFERENT label, i.e. across a collision front, where
 // the chains are two pixels long instead of running along the whole front.
-__device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst, const unsigned long long *__restrict__ cand, int p,
-                                               int myr, int Y, int X)
+// COH: every load / store goes to the L2 (agent scope), for the one-workgroup kernel that runs whole generations back to back: a cache
+// line it read in an earlier generation may be stale in the CU's vector cache once atomics have changed it in the L2.
+__device__ __forceinline__ unsigned long long mb_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int mb_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mb_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mb_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool COH = false>
+__device__ __forceinline__ bool mb_try_resolve(unsigned long long *st, const unsigned long long *cand, int p, int myr, int Y, int X)
 {
+    volatile unsigned long long *vst = st;
     const int y = p / X, x = p - y * X;
     const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
     int l0 = 0;
@@ -984,7 +961,7 @@ __device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (nb[k] < 0) continue;
-        const unsigned long long s = vst[nb[k]];
+        const unsigned long long s = COH ? mb_ld(st + nb[k]) : vst[nb[k]];
         const int l = st_lab(s);
         if (l > 0) {
             if (l0 == 0) l0 = l;
@@ -998,61 +975,12 @@ __device__ __forceinline__ bool mb_try_resolve(volatile unsigned long long *vst,
         bool pending = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if ((wait_mask >> k) & 1u) pending |= (int)(unsigned)(cand[nb[k]] & 0xffffffffULL) != l0;
+            if ((wait_mask >> k) & 1u) pending |= (int)(unsigned)((COH ? mb_ld(cand + nb[k]) : cand[nb[k]]) & 0xffffffffULL) != l0;
         if (pending) return false;
     }
-    vst[p] = pack_st(diff ? LINE_LAB : (int)(unsigned)(cand[p] & 0xffffffffULL), myr);
+    const unsigned long long out = pack_st(diff ? LINE_LAB : (int)(unsigned)((COH ? mb_ld(cand + p) : cand[p]) & 0xffffffffULL), myr);
+    if (COH) mb_st(st + p, out); else vst[p] = out;
     return true;
-}
-
-// One parallel pass over a list of the generation's pixels (list indices = ranks); the ones left waiting -- chains of
-// adjacent same-generation pixels along collision fronts, a pixel per pass -- are listed for the next pass.
-// src == nullptr: the whole generation (first pass); else the waiting list of the previous pass.
-__global__ void __launch_bounds__(256) k_mb_resolve(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                    const int *__restrict__ list, int nlist, const int *__restrict__ src,
-                                                    const int *__restrict__ nsrc, int Y, int X, int *__restrict__ pend,
-                                                    int *__restrict__ npend)
-{
-    __shared__ int s_items[4 * 256], s_count, s_base;
-    const BlockList bl{s_items, &s_count, &s_base};
-    const int n = src ? *nsrc : nlist;
-    // block-stride loop: later passes are launched for an expected count, whatever the real one is gets processed
-    for (int j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x) {
-        bl_init(bl);
-        const int j = j0 + threadIdx.x;
-        if (j < n) {
-            const int i = src ? src[j] : j;
-            const int p = list[i];
-            bool waiting = true;
-            for (int attempt = 0; attempt < 2 && waiting; ++attempt) waiting = !mb_try_resolve(st, cand, p, i + 1, Y, X);
-            if (waiting) bl_push(bl, i);
-        }
-        bl_flush(bl, pend, npend);
-        __syncthreads();
-    }
-}
-
-// tail: ONE block sweeps what is still waiting after the parallel passes until all are decided (every sweep decides at
-// least the smallest-ranked one).  One block: no host round trip per sweep, and the block's own stores are visible to
-// its (volatile) loads after the barrier.
-__global__ void __launch_bounds__(1024) k_mb_resolve_tail(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                          const int *__restrict__ list, const int *__restrict__ pend,
-                                                          const int *__restrict__ npend, int Y, int X, WsInfo *info)
-{
-    const int n = *npend;
-    volatile unsigned long long *vst = st;
-    int left = n;
-    for (int sweep = 0; sweep <= n && left > 0; ++sweep) {
-        int mine = 0;
-        for (int j = threadIdx.x; j < n; j += 1024) {
-            const int i = pend[j], p = list[i];
-            if (st_lab(vst[p]) != 0) continue;
-            if (!mb_try_resolve(vst, cand, p, i + 1, Y, X)) mine = 1;
-        }
-        __threadfence_block();
-        left = __syncthreads_count(mine);
-    }
-    if (threadIdx.x == 0 && left) info->unfinished = 1;   // only if the generation is inconsistent (never seen)
 }
 
 // ---- the generation loop without a host round trip per generation ------------------------------------------------------------------
@@ -1065,21 +993,26 @@ struct MbState {
     int keyspace;    // rank keys of the generation being ranked: 4 x ncur (generation 0: 4 x markers)
     int gen;         // generations completed
     int pcount[4];   // waiting-list counters of the resolve passes
-    int scan_total;  // (unused total of the key scan)
+    int flip;        // which of the two ranked-list buffers holds the generation that pushes (0: listA)
+    int small_gens;  // generations finished by the one-workgroup kernel (diagnostic)
+    int gsize[30];   // pixels of generation 1, 2, ... (diagnostic, TIP_WS_DEBUG)
 };
 
 __global__ void k_mb_state_init(MbState *S, int keyspace0)
 {
-    S->ncur = 0; S->nnext = 0; S->keyspace = keyspace0; S->gen = 0; S->scan_total = 0;
+    S->ncur = 0; S->nnext = 0; S->keyspace = keyspace0; S->gen = 0; S->flip = 0; S->small_gens = 0;
     for (int q = 0; q < 4; ++q) S->pcount[q] = 0;
+    for (int q = 0; q < 30; ++q) S->gsize[q] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_mb_push_list_dn(unsigned long long *__restrict__ st, unsigned long long *__restrict__ cand,
-                                                         const int *__restrict__ list, MbState *S, int *__restrict__ next, int Y, int X)
+                                                         const int *__restrict__ listA, const int *__restrict__ listB, MbState *S,
+                                                         int *__restrict__ next, int Y, int X)
 {
     __shared__ int s_items[4 * 256], s_count, s_base;
     const BlockList bl{s_items, &s_count, &s_base};
     const int nlist = S->ncur;
+    const int *__restrict__ list = S->flip ? listB : listA;
     for (int j0 = blockIdx.x * blockDim.x; j0 < nlist; j0 += gridDim.x * blockDim.x) {      // (block-uniform trip count: barriers inside)
         bl_init(bl);
         const int i = j0 + threadIdx.x;
@@ -1160,9 +1093,10 @@ __global__ void __launch_bounds__(256) k_mb_scan_add(int *__restrict__ out, cons
 // ranks of the generation; the key flags of the NEXT generation's key space (4 x this generation's pixels) are cleared on the way
 __global__ void __launch_bounds__(256) k_mb_assign_ranks_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
                                                             const int *__restrict__ next, const MbState *S, const int *__restrict__ drank,
-                                                            int *__restrict__ list, int *__restrict__ kflag_next)
+                                                            int *__restrict__ listA, int *__restrict__ listB, int *__restrict__ kflag_next)
 {
     const int nnext = S->nnext;
+    int *__restrict__ list = S->flip ? listA : listB;        // the generation being ranked goes to the OTHER buffer
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nnext; i += gridDim.x * blockDim.x) {
         const int u = next[i];
         const int r = drank[(unsigned)(cand[u] >> 32)];
@@ -1175,12 +1109,13 @@ __global__ void __launch_bounds__(256) k_mb_assign_ranks_dn(unsigned long long *
 
 // resolve pass p (0: the whole generation; else the waiting list of pass p - 1), device counts, grid-stride
 __global__ void __launch_bounds__(256) k_mb_resolve_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                       const int *__restrict__ list, MbState *S, int pass, const int *__restrict__ src,
-                                                       int Y, int X, int *__restrict__ pend)
+                                                       const int *__restrict__ listA, const int *__restrict__ listB, MbState *S, int pass,
+                                                       const int *__restrict__ src, int Y, int X, int *__restrict__ pend)
 {
     __shared__ int s_items[4 * 256], s_count, s_base;
     const BlockList bl{s_items, &s_count, &s_base};
     const int n = pass == 0 ? S->nnext : S->pcount[pass - 1];
+    const int *__restrict__ list = S->flip ? listA : listB;
     for (int j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x) {
         bl_init(bl);
         const int j = j0 + threadIdx.x;
@@ -1198,10 +1133,11 @@ __global__ void __launch_bounds__(256) k_mb_resolve_dn(unsigned long long *__res
 
 // the one-block tail of a generation, then the state moves on to the next generation
 __global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
-                                                             const int *__restrict__ list, const int *__restrict__ pend, MbState *S, int last_pass,
-                                                             int Y, int X, WsInfo *info)
+                                                             const int *__restrict__ listA, const int *__restrict__ listB,
+                                                             const int *__restrict__ pend, MbState *S, int last_pass, int Y, int X, WsInfo *info)
 {
     const int n = S->pcount[last_pass];
+    const int *__restrict__ list = S->flip ? listA : listB;
     volatile unsigned long long *vst = st;
     int left = n;
     for (int sweep = 0; sweep <= n && left > 0; ++sweep) {
@@ -1209,7 +1145,7 @@ __global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long 
         for (int j = threadIdx.x; j < n; j += 1024) {
             const int i = pend[j], p = list[i];
             if (st_lab(vst[p]) != 0) continue;
-            if (!mb_try_resolve(vst, cand, p, i + 1, Y, X)) mine = 1;
+            if (!mb_try_resolve(st, cand, p, i + 1, Y, X)) mine = 1;
         }
         __threadfence_block();
         left = __syncthreads_count(mine);
@@ -1220,7 +1156,120 @@ __global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long 
         S->ncur = nn;
         S->keyspace = 4 * nn;
         S->nnext = 0;
+        if (nn > 0 && S->gen < 30) S->gsize[S->gen] = nn;
         S->gen += nn > 0 ? 1 : 0;
+        S->flip ^= 1;
+        for (int q = 0; q < 4; ++q) S->pcount[q] = 0;
+    }
+}
+
+// Small generations, as many as follow each other, in ONE workgroup: the late generations of a frame are a few hundred to a few thousand
+// pixels (the flood's fronts meeting inside the boundary bands), and a generation of the grid-wide path is nine launches whatever its size.
+// Here a generation is: push (append counter in LDS), the key flags as BITS in LDS (4 x ncur of them), ranks from a scan of the words'
+// population counts, the ranked list, and resolve sweeps until nothing waits -- barriers instead of launches.  The kernel leaves as soon
+// as a generation is larger than `small` again (state and key flags as the grid-wide kernels expect them), or when the flood is over.
+constexpr int MB_SMALL_DEFAULT = 8192, MB_BATCH_DEFAULT = 4;
+constexpr int MBG_THREADS = 1024, MBG_WORDS = 4096;           // key bits: 4 x ncur <= 32 x MBG_WORDS
+constexpr int MB_SMALL_MAX = MBG_WORDS * 32 / 4;
+__global__ void __launch_bounds__(MBG_THREADS) k_mb_small_gens(unsigned long long *st, unsigned long long *cand, int *listA, int *listB,
+                                                               int *unordered, MbState *S, int small, int *kflag, int Y, int X, WsInfo *info)
+{
+    __shared__ unsigned bits[MBG_WORDS];
+    __shared__ int pre[MBG_WORDS];
+    __shared__ int wsum[MBG_THREADS / 64];
+    __shared__ int s_nnext;
+    int ncur = S->ncur, flip = S->flip, gen = S->gen;
+    if (ncur <= 0 || ncur > small) return;                    // (uniform)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int unfinished = 0, done = 0;
+    for (;;) {
+        int *cur = flip ? listB : listA, *nxt = flip ? listA : listB;
+        const int nwords = (4 * ncur + 31) >> 5;
+        for (int w = t; w < nwords; w += MBG_THREADS) bits[w] = 0u;
+        if (t == 0) s_nnext = 0;
+        __syncthreads();
+        // push: key = rank of the pusher * 4 + slot (up, left, right, down); the first push of a pixel appends it
+        for (int i = t; i < ncur; i += MBG_THREADS) {
+            const int p = mb_ld(cur + i);
+            const unsigned long long sp = mb_ld(st + p);
+            const int l = st_lab(sp);
+            if (l <= 0) continue;
+            const unsigned long long r4 = (unsigned long long)(unsigned)(st_tref(sp) - 1) * 4ULL;
+            const int y = p / X, x = p - y * X;
+            const int nb[4] = {y > 0 ? p - X : -1, x > 0 ? p - 1 : -1, x < X - 1 ? p + 1 : -1, y < Y - 1 ? p + X : -1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = nb[k];
+                if (u < 0 || mb_ld(st + u) != 0ULL) continue;
+                const unsigned long long val = ((r4 + (unsigned long long)k) << 32) | (unsigned)l;
+                if (atomicMin(&cand[u], val) == MB_NONE) mb_st(unordered + atomicAdd(&s_nnext, 1), u);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        const int nnext = s_nnext;
+        if (nnext > 0) {
+            for (int i = t; i < nnext; i += MBG_THREADS) {
+                const unsigned key = (unsigned)(mb_ld(cand + mb_ld(unordered + i)) >> 32);
+                atomicOr(&bits[key >> 5], 1u << (key & 31u));
+            }
+            __syncthreads();
+            int carry = 0;
+            for (int base = 0; base < nwords; base += MBG_THREADS) {
+                const int w = base + t;
+                const int c = w < nwords ? __popc(bits[w]) : 0;
+                int inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+                int woff = 0, total = 0;
+#pragma unroll
+                for (int q = 0; q < MBG_THREADS / 64; ++q) {
+                    const int v = wsum[q];
+                    woff += q < wave ? v : 0;
+                    total += v;
+                }
+                if (w < nwords) pre[w] = carry + woff + inc - c;
+                carry += total;
+                __syncthreads();
+            }
+            for (int i = t; i < nnext; i += MBG_THREADS) {
+                const int u = mb_ld(unordered + i);
+                const unsigned key = (unsigned)(mb_ld(cand + u) >> 32);
+                const int r = pre[key >> 5] + __popc(bits[key >> 5] & ((1u << (key & 31u)) - 1u));
+                mb_st(st + u, pack_st(0, r + 1));
+                mb_st(nxt + r, u);
+            }
+            __threadfence();
+            __syncthreads();
+            int left = nnext;
+            for (int sweep = 0; sweep <= nnext && left > 0; ++sweep) {
+                int mine = 0;
+                for (int i = t; i < nnext; i += MBG_THREADS) {
+                    const int p = mb_ld(nxt + i);
+                    if (st_lab(mb_ld(st + p)) != 0) continue;
+                    if (!mb_try_resolve<true>(st, cand, p, i + 1, Y, X)) mine = 1;
+                }
+                __threadfence();
+                left = __syncthreads_count(mine);
+            }
+            if (left) unfinished = 1;
+            if (t == 0 && gen < 30) S->gsize[gen] = nnext;
+            ++gen;
+            ++done;
+        }
+        flip ^= 1;
+        ncur = nnext;
+        if (ncur == 0 || ncur > small) break;
+    }
+    for (int i = t; i < 4 * ncur; i += MBG_THREADS) kflag[i] = 0;       // the grid-wide path ranks the next generation: its key flags start clean
+    if (t == 0) {
+        if (unfinished) info->unfinished = 1;
+        S->ncur = ncur; S->keyspace = 4 * ncur; S->nnext = 0; S->gen = gen; S->flip = flip; S->small_gens += done;
         for (int q = 0; q < 4; ++q) S->pcount[q] = 0;
     }
 }
@@ -1367,8 +1416,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         TIP_LAUNCH("mb_invert", k_mb_invert, dim3(cdiv(M, 256)), dim3(256), 0, (const unsigned *)order_d, E_d, (long)M);
         TIP_LAUNCH("mb_init", k_mb_init, dim3(cdiv(n, 256)), dim3(256), 0, st, (const int *)mrank, (const unsigned *)E_d, cand, n);
         // (b) generations: sizes on the device (MbState), launches queued MB_BATCH generations at a time, one look at the state per batch
-        int *cur_list = lists, *next_list = lists + n;     // next_list doubles as the unordered append buffer: the ranked
-        int *unordered = parent;                            // list is written from a separate buffer (parent is free here)
+        int *unordered = parent;                            // append buffer of a generation before it is ranked (parent is free here)
         MbState *S = ws.get<MbState>(1);
         const long nm = n - M;                              // non-marker pixels: the most a generation (and all of them together) can hold
         const long keycap_later = 4L * nm + 4;
@@ -1376,15 +1424,19 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
         if (!S || !csum) return TIP_ERR_NOMEM;
         TIP_LAUNCH("mb_state_init", k_mb_state_init, dim3(1), dim3(1), 0, S, (int)std::min<long>(4L * M, 0x7fffffffL));
         TIP_HIP(hipMemsetAsync(kflag, 0, (size_t)(4L * M) * sizeof(int), s));
-        constexpr int MB_BATCH = 8, MB_PASSES = 2;         // (pixels wait only across collision fronts: the second pass is already nearly empty, the tail takes what it leaves)
+        constexpr int MB_PASSES = 2;                        // (pixels wait only across collision fronts: the second pass is already nearly empty, the tail takes what it leaves)
+        const int mb_small = tune.mb_small < 0 ? MB_SMALL_DEFAULT : std::min(tune.mb_small, MB_SMALL_MAX);
+        const int mb_batch = tune.mb_batch > 0 ? std::min(tune.mb_batch, 64) : MB_BATCH_DEFAULT;
         const int lgrid = (int)std::max<long>(1, std::min<long>(cdiv(nm, 256), 1024));      // fixed grids, grid-stride loops over device counts
+        int *listA = lists, *listB = lists + n;             // ranked lists of the pushing / the pushed generation; MbState::flip says which is which
         MbState hS;
         for (int gen = 0;;) {
-            for (int b = 0; b < MB_BATCH; ++b, ++gen) {
+            for (int b = 0; b < mb_batch; ++b, ++gen) {
                 if (gen == 0)
                     TIP_LAUNCH("mb_push_markers", k_mb_push_markers, dim3(cdiv(X, 256), Y), dim3(256), 0, st, cand, unordered, &S->nnext, Y, X);
                 else
-                    TIP_LAUNCH("mb_push_list", k_mb_push_list_dn, dim3(lgrid), dim3(256), 0, st, cand, (const int *)cur_list, S, unordered, Y, X);
+                    TIP_LAUNCH("mb_push_list", k_mb_push_list_dn, dim3(lgrid), dim3(256), 0, st, cand, (const int *)listA, (const int *)listB, S,
+                               unordered, Y, X);
                 TIP_LAUNCH("mb_flag_keys", k_mb_flag_keys_dn, dim3(lgrid), dim3(256), 0, (const unsigned long long *)cand, (const int *)unordered,
                            (const MbState *)S, kflag);
                 const long keys = gen == 0 ? 4L * M : keycap_later;
@@ -1392,24 +1444,31 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                 TIP_LAUNCH("mb_scan_chunks", k_mb_scan_chunks, dim3(sgrid), dim3(256), 0, (const int *)kflag, drank, (const MbState *)S, csum);
                 TIP_LAUNCH("mb_scan_add", k_mb_scan_add, dim3(sgrid), dim3(256), 0, drank, (const MbState *)S, (const int *)csum);
                 TIP_LAUNCH("mb_assign_ranks", k_mb_assign_ranks_dn, dim3(lgrid), dim3(256), 0, st, (const unsigned long long *)cand,
-                           (const int *)unordered, (const MbState *)S, (const int *)drank, next_list, kflag);
+                           (const int *)unordered, (const MbState *)S, (const int *)drank, listA, listB, kflag);
                 // fate of the generation: parallel passes that ping-pong the list of waiting pixels, then the one-block tail, which
                 // also moves the state on to the next generation
                 for (int pass = 0; pass < MB_PASSES; ++pass) {
                     int *dst = pass & 1 ? pendB : pendA;
                     const int *src = pass == 0 ? nullptr : (pass & 1 ? pendA : pendB);
                     TIP_LAUNCH("mb_resolve", k_mb_resolve_dn, dim3(pass == 0 ? lgrid : std::max(1, lgrid >> (2 * pass))), dim3(256), 0, st,
-                               (const unsigned long long *)cand, (const int *)next_list, S, pass, src, Y, X, dst);
+                               (const unsigned long long *)cand, (const int *)listA, (const int *)listB, S, pass, src, Y, X, dst);
                 }
                 TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail_dn, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
-                           (const int *)next_list, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), S, MB_PASSES - 1, Y, X, info);
-                std::swap(cur_list, next_list);
+                           (const int *)listA, (const int *)listB, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), S, MB_PASSES - 1, Y, X, info);
+                // whatever small generations follow (usually all that are left) run in one workgroup
+                if (mb_small > 0)
+                    TIP_LAUNCH("mb_small_gens", k_mb_small_gens, dim3(1), dim3(MBG_THREADS), 0, st, cand, listA, listB, unordered, S, mb_small, kflag, Y, X, info);
             }
             TIP_HIP(hipMemcpyAsync(&hS, S, sizeof hS, hipMemcpyDeviceToHost, s));
             TIP_HIP(hipMemcpyAsync(&h, info, sizeof h, hipMemcpyDeviceToHost, s));      // (the same look: did every generation resolve?)
             TIP_HIP(hipStreamSynchronize(s));
             if (hS.ncur == 0) break;                        // the last generation pushed nothing: the flood is complete
             if (gen > 4 * (Y + X) + 64) return fail(TIP_ERR_HIP, "watershed: the two-valued flood does not terminate");
+        }
+        if (tune.ws_debug) {
+            fprintf(stderr, "[tip] two-valued flood: %d generations (%d in the one-workgroup kernel), sizes", hS.gen, hS.small_gens);
+            for (int q = 0; q < 30 && q < hS.gen; ++q) fprintf(stderr, " %d", hS.gsize[q]);
+            fprintf(stderr, "\n");
         }
         if (h.unfinished != 0) return fail(TIP_ERR_HIP, "watershed: a generation of the two-valued flood did not resolve");
     } else if (h.n_markers > 0) {

@@ -17,6 +17,7 @@ Deliberate deviations from the reference (documented in DESIGN.md):
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -157,6 +158,18 @@ def _percentile_linear_t(flat_sorted, q):
     if gamma >= 0.5:
         res = hi - diff * (1 - gamma)
     return res
+
+
+_FORWARD_GATES = {}
+_FORWARD_GATES_LOCK = threading.Lock()
+
+
+def _forward_gate(device_index):
+    with _FORWARD_GATES_LOCK:
+        g = _FORWARD_GATES.get(device_index)
+        if g is None:
+            g = _FORWARD_GATES[device_index] = {"lock": threading.Lock(), "event": None, "stream": None}
+        return g
 
 
 class _UNet(object):
@@ -428,6 +441,27 @@ class _UNet(object):
                 and self.filters == _FILTERS and self.bottleneck == 1024        # (the reference's widths, pl.py:60-69)
                 and x.shape[2] % 64 == 0 and x.shape[3] % 256 == 0 and shares_runtime_with_torch(x))
 
+    def _forward_gated(self, x, logits):
+        """One network at a time on a device.  Frames in flight (worker threads, each with its own stream: movie.py, bench.py) would
+        otherwise run their forward passes CONCURRENTLY -- the queues share the chip kernel by kernel, every pass takes N times as
+        long, all of them end together and the frames' tails (small kernels, host stages) then run together with nothing to
+        hide behind: the kernel trace shows the matrix cores idle for 8.5 % of the time (profiles/r04n_*).  Here a pass waits ON THE
+        DEVICE (stream.wait_event, no host stall) for the pass queued before it, so that the passes run back to back in ticket order
+        and the other frames' tails and projections fill in beside them.  TISSUE_HIP_UNET_SERIAL=0 restores the free-for-all."""
+        torch = self.torch
+        if os.environ.get("TISSUE_HIP_UNET_SERIAL", "1") == "0":
+            return self._forward_hip(x, logits)
+        gate = _forward_gate(x.device.index)
+        with gate["lock"]:
+            s = torch.cuda.current_stream(x.device)
+            if gate["event"] is not None and gate["stream"] != s.cuda_stream:
+                s.wait_event(gate["event"])
+            out = self._forward_hip(x, logits)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            gate["event"], gate["stream"] = ev, s.cuda_stream
+        return out
+
     def _forward_hip(self, x, logits):
         torch = self.torch
         mode = _unet_mode()
@@ -548,7 +582,7 @@ class _UNet(object):
         torch = self.torch
         F = torch.nn.functional
         if self.hip_path_ok(x):
-            return self._forward_hip(x, logits)
+            return self._forward_gated(x, logits)
         self.last_mode = "miopen"
         with torch.no_grad():
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
