@@ -13,8 +13,8 @@
 //      element to the root and sinks it towards the smaller child, the left one among equals) and upstream's push order
 //      (up, left, right, down; age = running push count).  The device still does everything around it: local minima,
 //      their connected-component labels in raster order, threshold and blur before, cell tables after.
-//      Cost: O(n log n) on one host core, ~0.3 us per pixel (about 1 s for a 2048^2 frame) -- the same class as the
-//      reference's own Cython loop; `flags` bit 2 tells the caller it ran.
+//      Cost: O(n log n) on one host core, ~0.1 us per pixel for integer-valued frames (see "the literal array heap" below;
+//      the reference's own Cython loop is ~0.3 us); `flags` bit 2 tells the caller it ran.
 //
 //  (2) flood_keyed_finish(): mode A (tip_watershed.hip) orders pixels by the static key (value, raster index).  When its
 //      tile rounds, pocket certificates, per-component endgame and wide pass all stall (plateaus of equal value larger
@@ -38,108 +38,164 @@ inline uint64_t order_key(double d)
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
 }
 
-struct Entry {          // 16 bytes: three entries per 48 bytes of cache instead of two per 48 with upstream's 24-byte struct
-    uint64_t v;         // order_key(value)
-    uint64_t ai;        // age << 31 | padded pixel index   (age < 2^33: 4 pushes per pixel of a < 2^31 pixel image)
-};
-constexpr uint64_t IDX_MASK = (1ULL << 31) - 1;
-inline bool smaller(const Entry &a, const Entry &b)
-{
-    if (a.v != b.v) return a.v < b.v;
-    return (a.ai >> 31) < (b.ai >> 31);      // age only: entries that tie in value AND age are "not smaller" either way
-}
+// ---- the literal array heap ------------------------------------------------------------------------------------------------
+// Bit parity needs upstream's heap ARRAY at every moment (header above), not its speed.  What is free: how an entry is stored and how
+// a sift is carried out, as long as every element ends in the slot upstream's code would put it.
+//   * pop: upstream moves the last element x to the root and sinks it towards the smaller child (the left one among equals) while that
+//     child is smaller than x.  The path of smaller children does not depend on x, so the hole is walked down that path to a leaf
+//     without looking at x (one comparison and one move per level, no unpredictable exit branch), and x then climbs back while its
+//     parent on the path is NOT smaller than x -- it stops under the last element smaller than it, which is the slot the top-down
+//     sink ends in: above every path element >= x (equal keys exist only between seeds, and upstream leaves x above them too).
+//     x comes from the bottom row, so the climb is a step or two.
+//   * push: the entry climbs while strictly smaller than its parent (upstream's rule), moved with a hole instead of swaps.
+//   * the children two levels down are prefetched while a level is decided; the cells of the next few pops are prefetched from the
+//     heap's top right after a pop (the pops of one level are scattered over the whole frame: three cache misses per pop otherwise).
+// Keys: integer-valued landscapes below 2^31 (the uint16 frames this stage exists for) order by ONE 64-bit word,
+// value << 33 | age; anything else by (sortable image of the double, age).  Measured on a 2048^2 uint16 landscape: 3.3 x faster than
+// the swap-based heap with 24-byte comparisons it replaces (same output, tests/test_ws_serial_host.py).
+constexpr int AGE_BITS = 33;                      // age < 2^33: four pushes per pixel of a < 2^31 pixel image
+constexpr uint64_t AGE_MASK = (1ULL << AGE_BITS) - 1;
 
-struct ArrayHeap {
-    std::vector<Entry> d;
-    void push(const Entry &e)
+struct KeyInt {                                   // value << 33 | age
+    uint64_t k;
+    static KeyInt make(uint32_t value, uint64_t age) { return KeyInt{((uint64_t)value << AGE_BITS) | age}; }
+    bool smaller(const KeyInt &o) const { return k < o.k; }
+    bool seed() const { return (k & AGE_MASK) == 0; }
+};
+struct KeyF64 {                                   // (order_key(value), age)
+    uint64_t v, age;
+    static KeyF64 make(uint64_t value, uint64_t age) { return KeyF64{value, age}; }
+    bool smaller(const KeyF64 &o) const { return v < o.v || (v == o.v && age < o.age); }   // entries that tie in value AND age are "not smaller" either way
+    bool seed() const { return age == 0; }
+};
+
+template <typename Key> struct HeapEntry { Key key; uint32_t pixel; };
+
+template <typename Key> struct ArrayHeap {
+    typedef HeapEntry<Key> E;
+    std::vector<E> store;
+    E *d = nullptr;
+    size_t n = 0;
+    explicit ArrayHeap(size_t cap) { store.resize(cap + 8); d = store.data(); }
+    void push(const E &e)
     {
-        size_t child = d.size();
-        d.push_back(e);
-        while (child > 0) {
-            const size_t parent = (child + 1) / 2 - 1;
-            if (!smaller(d[child], d[parent])) break;
-            std::swap(d[child], d[parent]);
-            child = parent;
+        if (n + 8 > store.size()) { store.resize(store.size() * 2); d = store.data(); }
+        size_t c = n++;
+        while (c > 0) {
+            const size_t parent = (c - 1) >> 1;
+            if (!e.key.smaller(d[parent].key)) break;
+            d[c] = d[parent];
+            c = parent;
         }
+        d[c] = e;
     }
-    Entry pop()
+    E pop()
     {
-        const Entry top = d[0];
-        const size_t n = d.size() - 1;
-        if (n == 0) { d.pop_back(); return top; }
-        d[0] = d[n];
-        d.pop_back();
+        const E top = d[0];
+        const size_t m = --n;
+        if (m == 0) return top;
+        const E x = d[m];
         size_t i = 0;
         for (;;) {
-            const size_t l = 2 * i + 1, r = l + 1;
-            if (l >= n) break;
-            size_t s = i;
-            if (smaller(d[l], d[i])) s = l;
-            if (r < n && smaller(d[r], d[s])) s = r;
-            if (s == i) break;
-            std::swap(d[i], d[s]);
+            const size_t l = 2 * i + 1;
+            if (l >= m) break;
+            __builtin_prefetch(&d[8 * i + 7]);
+            __builtin_prefetch(&d[8 * i + 11]);
+            const size_t r = l + 1 < m ? l + 1 : l;
+            const size_t s = d[r].key.smaller(d[l].key) ? r : l;
+            d[i] = d[s];
             i = s;
         }
+        while (i > 0) {
+            const size_t parent = (i - 1) >> 1;
+            if (d[parent].key.smaller(x.key)) break;
+            d[i] = d[parent];
+            i = parent;
+        }
+        d[i] = x;
         return top;
     }
 };
+
+// one pixel of the padded frame: lab -1 = closed (outside the image, or a line: upstream's mask), 0 = undecided, > 0 = label
+template <typename V> struct FloodCell { int32_t lab; V value; };
+
+template <typename Key, typename V, typename ValueOf>
+int flood_exact_t(const double *img, const int32_t *markers, int32_t *labels, int Y, int X, ValueOf value_of)
+{
+    typedef FloodCell<V> Cell;
+    typedef HeapEntry<Key> E;
+    const long PX = (long)X + 2, PN = ((long)Y + 2) * PX;
+    std::vector<Cell> cells((size_t)PN + 1, Cell{-1, 0});
+    Cell *c = cells.data();
+    long nmark = 0;
+    for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x) {
+            const long p = (long)(y + 1) * PX + x + 1, i = (long)y * X + x;
+            c[p].lab = markers[i] > 0 ? markers[i] : 0;
+            c[p].value = value_of(img[i]);
+            nmark += markers[i] > 0;
+        }
+    ArrayHeap<Key> hp((size_t)std::max<long>(1024, nmark + (long)Y * X / 2));
+    for (long p = 0; p < PN; ++p)
+        if (c[p].lab > 0) hp.push(E{Key::make(c[p].value, 0), (uint32_t)p});     // age 0, raster order
+    const long nb[4] = {-PX, -1, 1, PX};     // upstream's push order: up, left, right, down
+    uint64_t age = 1;
+    while (hp.n) {
+        const E e = hp.pop();
+        if (hp.n > 2)
+            for (int t = 0; t < 3; ++t) {
+                const Cell *z = c + hp.d[t].pixel;
+                __builtin_prefetch(z); __builtin_prefetch(z - PX); __builtin_prefetch(z + PX);
+            }
+        const long p = (long)e.pixel;
+        const bool seed = e.key.seed();
+        const int32_t own = c[p].lab;
+        if (!seed && own != 0) continue;                     // reached earlier through another neighbour, or a line by now
+        const Cell q[4] = {c[p + nb[0]], c[p + nb[1]], c[p + nb[2]], c[p + nb[3]]};
+        // upstream's _diff_neighbors: a pixel that is no longer open, or whose open neighbours carry two labels, is a line
+        bool line = own < 0;
+        int32_t l0 = 0;
+        if (!line)
+            for (int k = 0; k < 4; ++k) {
+                const int32_t l = q[k].lab;
+                if (l < 0) continue;
+                if (l0 == 0) l0 = l;
+                else if (l != 0 && l != l0) { line = true; break; }
+            }
+        if (line) { c[p].lab = -1; continue; }
+        // the entry that pops first for a pixel was pushed by its earliest-labelled neighbour, and with no second label
+        // around, every labelled neighbour carries that neighbour's label: upstream's output[source]
+        if (!seed) c[p].lab = l0;
+        for (int k = 0; k < 4; ++k) {
+            if (q[k].lab != 0) continue;
+            ++age;
+            hp.push(E{Key::make(q[k].value, age), (uint32_t)(p + nb[k])});
+        }
+    }
+    for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x) {
+            const int32_t l = c[(long)(y + 1) * PX + x + 1].lab;
+            labels[(long)y * X + x] = l > 0 ? l : 0;
+        }
+    return TIP_OK;
+}
 
 }  // namespace
 
 // img, markers, labels: Y x X row-major.  markers > 0 are the seeds; labels receives the flood (0 = line / unreached).
 int flood_exact(const double *img, const int32_t *markers, int32_t *labels, int Y, int X)
 {
-    const long PX = (long)X + 2, PN = ((long)Y + 2) * PX;
-    if (PN > (long)IDX_MASK) return fail(TIP_ERR_ARG, "watershed: image too large for the serial stage");
-    std::vector<int32_t> out((size_t)PN, 0);
-    std::vector<uint8_t> open((size_t)PN, 0);     // upstream's mask: 1 inside the image until the pixel becomes a line
-    std::vector<uint64_t> key((size_t)PN, 0);
-    ArrayHeap hp;
-    long nmark = 0;
-    for (int y = 0; y < Y; ++y)
-        for (int x = 0; x < X; ++x) {
-            const long p = (long)(y + 1) * PX + x + 1;
-            const long i = (long)y * X + x;
-            out[(size_t)p] = markers[i];
-            open[(size_t)p] = 1;
-            key[(size_t)p] = order_key(img[i]);
-            nmark += markers[i] > 0;
-        }
-    hp.d.reserve((size_t)std::max<long>(1024, nmark + (long)Y * X / 2));
-    for (long p = 0; p < PN; ++p)
-        if (out[(size_t)p] > 0) hp.push(Entry{key[(size_t)p], (uint64_t)p});     // age 0, raster order
-    const long nb[4] = {-PX, -1, 1, PX};
-    uint64_t age = 1;
-    while (!hp.d.empty()) {
-        const Entry e = hp.pop();
-        const long p = (long)(e.ai & IDX_MASK);
-        const bool seed = (e.ai >> 31) == 0;
-        if (!seed && out[(size_t)p] != 0) continue;          // reached earlier through another neighbour
-        // upstream's _diff_neighbors: a pixel that is no longer open, or whose open neighbours carry two labels, is a line
-        bool line = !open[(size_t)p];
-        int32_t l0 = 0;
-        if (!line)
-            for (int k = 0; k < 4; ++k) {
-                const long q = p + nb[k];
-                if (!open[(size_t)q]) continue;
-                const int32_t l = out[(size_t)q];
-                if (l0 == 0) l0 = l;
-                else if (l != 0 && l != l0) { line = true; break; }
-            }
-        if (line) { open[(size_t)p] = 0; continue; }
-        // the entry that pops first for a pixel was pushed by its earliest-labelled neighbour, and with no second label
-        // around, every labelled neighbour carries that neighbour's label: upstream's output[source]
-        if (!seed) out[(size_t)p] = l0;
-        for (int k = 0; k < 4; ++k) {
-            const long q = p + nb[k];
-            if (!open[(size_t)q] || out[(size_t)q] != 0) continue;
-            ++age;
-            hp.push(Entry{key[(size_t)q], (age << 31) | (uint64_t)q});
-        }
+    const long PX = (long)X + 2, PN = ((long)Y + 2) * PX, n = (long)Y * X;
+    if (PN >= (1L << 31)) return fail(TIP_ERR_ARG, "watershed: image too large for the serial stage");
+    bool small_ints = true;                       // every value a whole number in [0, 2^31): one-word keys
+    for (long i = 0; i < n && small_ints; ++i) {
+        const double v = img[i];
+        small_ints = v >= 0.0 && v < 2147483648.0 && v == (double)(uint32_t)v;
     }
-    for (int y = 0; y < Y; ++y)
-        for (int x = 0; x < X; ++x) labels[(long)y * X + x] = out[(size_t)((long)(y + 1) * PX + x + 1)];
-    return TIP_OK;
+    if (small_ints)
+        return flood_exact_t<KeyInt, uint32_t>(img, markers, labels, Y, X, [](double v) { return (uint32_t)v; });
+    return flood_exact_t<KeyF64, uint64_t>(img, markers, labels, Y, X, [](double v) { return order_key(v); });
 }
 
 // ---- mode A finisher ------------------------------------------------------------------------------------------------------
