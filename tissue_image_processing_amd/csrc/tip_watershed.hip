@@ -1132,7 +1132,8 @@ __global__ void __launch_bounds__(256) k_mb_resolve_dn(unsigned long long *__res
 }
 
 // the one-block tail of a generation, then the state moves on to the next generation
-__global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
+constexpr int MBT_THREADS = 256;
+__global__ void __launch_bounds__(MBT_THREADS) k_mb_resolve_tail_dn(unsigned long long *__restrict__ st, const unsigned long long *__restrict__ cand,
                                                              const int *__restrict__ listA, const int *__restrict__ listB,
                                                              const int *__restrict__ pend, MbState *S, int last_pass, int Y, int X, WsInfo *info)
 {
@@ -1142,7 +1143,7 @@ __global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long 
     int left = n;
     for (int sweep = 0; sweep <= n && left > 0; ++sweep) {
         int mine = 0;
-        for (int j = threadIdx.x; j < n; j += 1024) {
+        for (int j = threadIdx.x; j < n; j += MBT_THREADS) {
             const int i = pend[j], p = list[i];
             if (st_lab(vst[p]) != 0) continue;
             if (!mb_try_resolve(st, cand, p, i + 1, Y, X)) mine = 1;
@@ -1169,7 +1170,11 @@ __global__ void __launch_bounds__(1024) k_mb_resolve_tail_dn(unsigned long long 
 // population counts, the ranked list, and resolve sweeps until nothing waits -- barriers instead of launches.  The kernel leaves as soon
 // as a generation is larger than `small` again (state and key flags as the grid-wide kernels expect them), or when the flood is over.
 constexpr int MB_SMALL_DEFAULT = 8192, MB_BATCH_DEFAULT = 4;
-constexpr int MBG_THREADS = 1024, MBG_WORDS = 4096;           // key bits: 4 x ncur <= 32 x MBG_WORDS
+// 256 threads and 8 KB of LDS, like every kernel of this flood: a workgroup of that size (<= 64 registers a lane) finds room on a CU
+// BESIDE the two waves per SIMD of another frame's convolution kernel (220 registers each of 512); the 1024-thread workgroups these
+// two kernels had first waited for a convolution workgroup to retire -- 0.2 ms per launch, 5 ms of latency per frame in the kernel
+// trace of the headline.  (Latency only: an A/B on one box shows the same frames/s either way, the frame's worker thread has that slack.)
+constexpr int MBG_THREADS = 256, MBG_WORDS = 1024;            // key bits: 4 x ncur <= 32 x MBG_WORDS
 constexpr int MB_SMALL_MAX = MBG_WORDS * 32 / 4;
 __global__ void __launch_bounds__(MBG_THREADS) k_mb_small_gens(unsigned long long *st, unsigned long long *cand, int *listA, int *listB,
                                                                int *unordered, MbState *S, int small, int *kflag, int Y, int X, WsInfo *info)
@@ -1453,7 +1458,7 @@ int watershed_dev(const double *img, int32_t *labels, int Y, int X, int wsl, int
                     TIP_LAUNCH("mb_resolve", k_mb_resolve_dn, dim3(pass == 0 ? lgrid : std::max(1, lgrid >> (2 * pass))), dim3(256), 0, st,
                                (const unsigned long long *)cand, (const int *)listA, (const int *)listB, S, pass, src, Y, X, dst);
                 }
-                TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail_dn, dim3(1), dim3(1024), 0, st, (const unsigned long long *)cand,
+                TIP_LAUNCH("mb_resolve_tail", k_mb_resolve_tail_dn, dim3(1), dim3(MBT_THREADS), 0, st, (const unsigned long long *)cand,
                            (const int *)listA, (const int *)listB, (const int *)((MB_PASSES - 1) & 1 ? pendB : pendA), S, MB_PASSES - 1, Y, X, info);
                 // whatever small generations follow (usually all that are left) run in one workgroup
                 if (mb_small > 0)

@@ -1,37 +1,50 @@
-"""Timeline analysis of a rocprofv3 --kernel-trace CSV: how much of the small kernels' time overlaps the network's convolution kernels of other
-frames.  usage: python tools/overlap.py <kernel_trace.csv>"""
+"""Timeline analysis of a rocprofv3 --kernel-trace CSV of the headline leg (bench.py --workload unet): are the network's convolution kernels
+running all the time, and do the forward passes of the frames in flight run one after another or on top of each other?
+usage: python tools/overlap.py <kernel_trace.csv> [label [warmup steps]]"""
 import csv, sys, collections
+
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", ""), r.get("Stream_Id", "")))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60], r.get("Queue_Id", "")))
 rows.sort()
-t0, t1 = rows[0][0], max(r[1] for r in rows)
-# restrict to the last 60 % of the run (the timed region; the first part is warm-up / build)
-lo = t0 + int(0.4 * (t1 - t0))
-rows = [r for r in rows if r[0] >= lo]
-span = (max(r[1] for r in rows) - rows[0][0]) / 1e6
-conv = [r for r in rows if "k_unet" in r[2]]
-other = [r for r in rows if "k_unet" not in r[2]]
+t0 = rows[0][0]
+firsts = [a for a, b, n, q in rows if "k_unet_conv_first" in n]
+# the timed region: the first run of forward passes (starts less than 260 ms apart) that holds warm-up + steps of them; its last `steps`
+warmup, steps = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3, 12)
+runs, cur = [], [firsts[0]]
+for a in firsts[1:]:
+    if a - cur[-1] > 260e6:
+        runs.append(cur)
+        cur = []
+    cur.append(a)
+runs.append(cur)
+run = next(r for r in runs if len(r) >= warmup + steps)
+lo, hi = run[warmup], run[warmup + steps - 1]
+sel = [r for r in rows if r[0] >= lo and r[1] <= hi]
+frames = steps - 1
+
 def union(iv):
-    iv = sorted(iv); out = []; 
-    for a, b in iv:
-        if out and a <= out[-1][1]: out[-1][1] = max(out[-1][1], b)
-        else: out.append([a, b])
+    out = []
+    for a, b in sorted(iv):
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
     return out
-cu = union([(a, b) for a, b, *_ in conv]); ou = union([(a, b) for a, b, *_ in other]); au = union([(a, b) for a, b, *_ in rows])
+
+
 L = lambda u: sum(b - a for a, b in u) / 1e6
-def inter(u, v):
-    i = j = 0; s = 0
-    while i < len(u) and j < len(v):
-        a = max(u[i][0], v[j][0]); b = min(u[i][1], v[j][1])
-        if b > a: s += b - a
-        if u[i][1] < v[j][1]: i += 1
-        else: j += 1
-    return s / 1e6
-print("window %.1f ms: conv sum %.1f union %.1f | other sum %.1f union %.1f | any-kernel union %.1f (idle %.1f) | other∩conv %.1f ms" % (
-    span, sum(b - a for a, b, *_ in conv) / 1e6, L(cu), sum(b - a for a, b, *_ in other) / 1e6, L(ou), L(au), span - L(au), inter(cu, ou)))
-print("queues:", collections.Counter((r[3]) for r in rows).most_common(8))
-by = collections.defaultdict(lambda: [0, 0.0])
-for a, b, n, *_ in other:
-    k = n.split("(")[0][:60]; by[k][0] += 1; by[k][1] += (b - a) / 1e6
-for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]: print("  %-60s %5d  %.2f ms" % (k, c, t))
+span = (hi - lo) / 1e6
+conv = [(a, b) for a, b, n, q in sel if "k_unet" in n]
+oth = [(a, b) for a, b, n, q in sel if "k_unet" not in n]
+cu, au = union(conv), union(conv + oth)
+label = sys.argv[2] if len(sys.argv) > 2 else ""
+print("%s window %.1f ms, %d forward passes started (%.2f ms per frame under the tracer)" % (label, span, frames, span / max(frames, 1)))
+print("  network kernels: sum of durations %.1f ms, union %.1f ms (%.1f %% of the window; concurrency %.2f)" % (
+    sum(b - a for a, b in conv) / 1e6, L(cu), 100 * L(cu) / span, sum(b - a for a, b in conv) / 1e6 / L(cu)))
+print("  other kernels:   sum %.1f ms, union %.1f ms" % (sum(b - a for a, b in oth) / 1e6, L(union(oth))))
+print("  no network kernel running: %.1f ms = %.1f %% of the window; no kernel at all: %.1f ms = %.1f %%" % (
+    span - L(cu), 100 * (span - L(cu)) / span, span - L(au), 100 * (span - L(au)) / span))
+starts = sorted(a for a in firsts if lo <= a <= hi)
+gaps = [(starts[i + 1] - starts[i]) / 1e6 for i in range(len(starts) - 1)]
+print("  starts of consecutive forward passes, ms apart:", " ".join("%.0f" % g for g in gaps[:24]))
