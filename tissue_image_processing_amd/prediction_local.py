@@ -172,6 +172,20 @@ def _forward_gate(device_index):
         return g
 
 
+_SIDE = threading.local()
+
+
+def _side_streams(device):
+    """three extra streams per (thread, device) for the transposed convolution's parity classes"""
+    import torch
+    d = getattr(_SIDE, "streams", None)
+    if d is None:
+        d = _SIDE.streams = {}
+    if device.index not in d:
+        d[device.index] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return d[device.index]
+
+
 class _UNet(object):
     """3-level U-Net of pl.py:31-72 as explicit torch functional calls (NCHW, channels_last memory format).
 
@@ -475,6 +489,8 @@ class _UNet(object):
         D = lambda t: ctypes.c_void_p(t.data_ptr())
 
         trace = getattr(self, "trace", None)      # tools/unet_layers.py: [(layer, flop, event, event)] per launch
+        tconv_mode = os.environ.get("TISSUE_HIP_UNET_TCONV", "split")
+        side = _side_streams(x.device) if tconv_mode == "parallel" else None
 
         def timed(name, flop, fn):
             if trace is None:
@@ -489,7 +505,8 @@ class _UNet(object):
         def buf(h, w, c):
             return torch.empty((planes, h, w, c), dtype=torch.float16 if fmt else torch.bfloat16, device=x.device)
 
-        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None, fused_t=False):
+        def conv(name, src, skip, h, w, bn, out=None, oh=None, ow=None, sy=1, sx=1, oy=0, ox=0, bias=None, pooled=None, head=None, fused_t=False,
+                 on=None):
             wp, dy, dx, inv = hw[name][:4]
             cout = wp.shape[2] * 128
             d = _ConvDesc()
@@ -520,7 +537,7 @@ class _UNet(object):
             d.pool_out = pooled.data_ptr() if pooled is not None else None
             timed("%s %dx%d %d+%d->%d x%d taps" % (name, h, w, d.c0, d.c1, cout // 4 if fused_t else cout, 9 if fused_t else len(dy)),
                   2.0 * h * w * (9 * (cout // 4) if fused_t else len(dy) * cout) * (d.c0 + d.c1),
-                  lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream)))
+                  lambda: _lib.check(lib.tip_unet_conv_dev(ctypes.byref(d), stream if on is None else ctypes.c_void_p(on.cuda_stream))))
             return out
 
         def double(blk, src, skip, h, w, first=False, pooled=None, head=None):
@@ -554,12 +571,30 @@ class _UNet(object):
                 name = "u%d.t" % i
                 cout = hw[name + ".00"][0].shape[2] * 128
                 up = buf(2 * h, 2 * w, cout)
-                if planes == 2 and os.environ.get("TISSUE_HIP_UNET_TCONV", "split") == "fused":
+                if planes == 2 and tconv_mode == "fused":
                     # ONE launch for the four output parity classes (nine products per staged tile; bit-identical).  Measured SLOWER
                     # than the four launches (6.44 against 6.02 ms over the three layers at 2048^2): a workgroup then covers 32 output
                     # channels and its four steps per chunk carry 24 / 12 / 12 / 6 MFMAs per wave behind a barrier each, where the
                     # four-tap class launch carries 24 behind each -- the per-step barrier cost outweighs the shared staging
                     conv(name + ".fused", cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, fused_t=True)
+                elif tconv_mode == "parallel":
+                    # the four parity classes side by side on four streams (they read one tensor and write disjoint pixels): the idea was
+                    # that the one- and two-tap launches (bound by the L2 -> LDS copies of a tile they use once or twice) and the four-tap
+                    # launch (bound by the matrix pipe) fill each other's gaps.  Measured SLOWER: forward pass 49.7 / 50.0 ms against
+                    # 48.0 / 48.8 ms on one box -- a 512-thread workgroup has its CU to itself whichever launch it belongs to, so nothing
+                    # overlaps inside a CU and the fork / join events add their latency.  An experiment switch, like "fused".
+                    main = torch.cuda.current_stream(x.device)
+                    fork = torch.cuda.Event()
+                    fork.record(main)
+                    for k, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                        on = main if k == 0 else side[k - 1]
+                        if k:
+                            on.wait_event(fork)
+                        conv("%s.%d%d" % (name, py, px), cur, None, h, w, None, out=up, oh=2 * h, ow=2 * w, sy=2, sx=2, oy=py, ox=px, bias=name, on=on)
+                        if k:
+                            join = torch.cuda.Event()
+                            join.record(on)
+                            main.wait_event(join)
                 else:
                     for py in (0, 1):
                         for px in (0, 1):
