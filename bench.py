@@ -721,7 +721,8 @@ def main():
                 r["issued_frac_of_bf16_peak"] = r["issued_tflops"] / info["issued_peak_tflops"]
                 r["note"] = ("`peak` is the nominal dense 16-bit MFMA peak / the products per term; back-to-back 32x32x16 MFMAs from registers "
                              "with random operand bits sustain 1.70-1.75 PFLOP/s in fp16 and 1.85-1.94 in bf16 (68-78 % of 2.5) at a "
-                             "power-limited 1.7-1.9 GHz on this chip (tools/ubench/mfma_f16_rate.hip, profiles/r04a_mfma_*_rate*.txt)")
+                             "power-limited 1.7-1.9 GHz on this chip (tools/ubench/mfma_f16_rate.hip, profiles/r04a_mfma_*_rate*.txt); "
+                             "the board reads 1400 W, its cap, for the whole forward pass (tools/power_probe.py, profiles/r04n_unet_power.txt)")
         return r
 
     def unet_modes_record():
