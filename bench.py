@@ -857,6 +857,9 @@ def main():
                        "baseline_config": ("configs[2]: 2048x2048 z=30 single frame, full pipeline (projection -> filter -> U-Net seg -> "
                                            "watershed/CCL)") if workload == "unet" else "the classical variant of configs[2] (no network)",
                        "frames_per_step": world, "frames_in_flight_per_gpu": leg["nthreads"], "includes_h2d_upload": False,
+                       "network_passes_of_frames_in_flight": (None if workload != "unet" else
+                                                              "concurrent (TISSUE_HIP_UNET_SERIAL=0)" if os.environ.get("TISSUE_HIP_UNET_SERIAL", "1") == "0"
+                                                              else "one after the other on the device, other frames' projections / tails beside them"),
                        "parallelism": "frame-sharded dp%d, no data-path collective" % world},
             "value_with_pcie": head.get("value_with_pcie"), "with_pcie": head.get("with_pcie"),
             "roofline": head["roofline"], "roofline_timed_region": head["roofline_timed_region"], "roofline_valu": head["roofline_valu"],
