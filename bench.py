@@ -327,9 +327,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps of the headline leg (default: 16 for the U-Net workload, 64 for classical / projection, "
+                    help="timed steps of the headline leg (default: 30 for the U-Net workload, 64 for classical / projection, "
                          "16 for --workload movie, whose every frame is a distinct synthetic stack kept in pinned memory)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 3 for the U-Net workload, else 8)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 6 for the U-Net workload, else 8)")
     ap.add_argument("--size", type=int, nargs=3, default=[2048, 2048, 30], metavar=("Y", "X", "Z"))
     ap.add_argument("--workload", default="auto", choices=["auto", "projection", "classical", "unet", "movie"],
                     help="auto = unet = BASELINE config 3 as written (the classical variant rides along as a secondary leg)")
@@ -344,9 +344,9 @@ def main():
     args = ap.parse_args()
     workload = "unet" if args.workload == "auto" else args.workload
     if args.steps is None:
-        args.steps = {"movie": 16, "unet": 16}.get(workload, 64)
+        args.steps = {"movie": 16, "unet": 30}.get(workload, 64)     # (1.6 s of timed region: run-to-run spread of a 16-step region was 3 %)
     if args.warmup is None:
-        args.warmup = 3 if workload == "unet" else 8
+        args.warmup = 6 if workload == "unet" else 8
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
