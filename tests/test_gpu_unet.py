@@ -250,7 +250,7 @@ def test_unet_leg_three_frames_in_flight_every_step_exact():
     from oracle import oracle as orc
     from tissue_image_processing_amd import prediction_local as pl, synthetic, _lib
     N, STEPS, THREADS = 2048, 2, 3
-    results, errors = {}, []
+    results, errors, base = {}, [], {}
 
     def make_image(seed):
         sites = synthetic.make_sites(N, N, seed=seed)[0]
@@ -270,6 +270,7 @@ def test_unet_leg_three_frames_in_flight_every_step_exact():
                 pred = pl.SegmentationPredictor(None, images[k].shape)
                 padded, _ = pred.prepare_image(images[k])
                 pred.model.calibrate_head(padded, 0.5)
+                base[k] = pred.model.forward(padded)[0, 0].cpu().numpy()     # (before the threads are released together)
                 start.wait()
                 for step in range(STEPS):
                     padded, npad = pred.prepare_image(images[k])
@@ -290,6 +291,9 @@ def test_unet_leg_three_frames_in_flight_every_step_exact():
     assert len(results) == THREADS * STEPS
     for (k, step), (p0, lab, hc, flags) in sorted(results.items()):
         assert flags & _lib.WS_FLAG_TWO_VALUED and not (flags & (_lib.WS_FLAG_SERIAL_EXACT | _lib.WS_FLAG_SERIAL_FINISH)), (k, step, flags)
+        # the network passes of the three threads are ordered on the device (prediction_local._forward_gated): same input, same bits,
+        # whatever ran beside the pass
+        np.testing.assert_array_equal(p0, base[k])
         closed = orc.erosion(orc.dilation(255.0 * (p0 > np.float32(0.1)), 5), 5)
         hc_ref = orc.erosion(closed, 7)
         np.testing.assert_array_equal(hc, hc_ref)
