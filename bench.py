@@ -128,13 +128,18 @@ def cpu_baseline_worker(Ys, Xs, Z, workload, threads, seg=0):
         t_fwd = time.perf_counter() - t1
         fwd_px = n * n
         t1 = time.perf_counter()
-        lab = orc.closing_tail(p[0, 0].numpy().astype(np.float64))[0]
+        p0 = np.ascontiguousarray(p[0, 0].numpy())                        # float32, as Keras hands it to pl.py:168's `> 0.1`
+        lab, hc = orc.closing_tail(p0)[:2]
         orc.frame_cellinfo(lab)
         t_seg = (time.perf_counter() - t1) * (Ys * Xs) / float(fwd_px)     # the tail ran on the network's crop
+    keep = os.environ.get("TIP_BENCH_PARITY_OUT")
+    if keep:          # what this sample computed, for the parent's `label_parity` record (the GPU path on the same frame, compared after the timed legs)
+        extra = {"p0": p0, "hc": hc} if workload == "unet" else {}
+        np.savez(keep, proj=proj, zmap=zmap, lab=lab, **extra)
     print("CPU_BASELINE_SECONDS %.6f %.6f %.6f %d" % (t_proj, t_seg, t_fwd, fwd_px))
 
 
-def cpu_baseline(sample_yx, Z, workload, nproc, threads=1, seg=0):
+def cpu_baseline(sample_yx, Z, workload, nproc, threads=1, seg=0, keep=None):
     """Runs the sample in `nproc` child processes at once (started BEFORE this process touches the GPU) and returns the
     list of per-process (projection s, segmentation s, network s, network pixels): nproc = 1 is the single-process figure,
     nproc = host cores the embarrassingly parallel "N frames on N processes" one (scipy.ndimage / skimage are
@@ -143,6 +148,9 @@ def cpu_baseline(sample_yx, Z, workload, nproc, threads=1, seg=0):
     Ys, Xs = sample_yx
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(Ys), str(Xs), str(Z), workload, str(threads), str(seg)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS=str(threads))
+    env.pop("TIP_BENCH_PARITY_OUT", None)
+    if keep and nproc == 1:
+        env["TIP_BENCH_PARITY_OUT"] = keep
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(nproc)]
     secs = []
     for p in procs:
@@ -170,12 +178,15 @@ def cpu_baseline_record(Y, X, Z, workload):
         t_proj, t_seg, t_fwd, fwd_px = rec
         return (t_proj + t_seg) * scale + (t_fwd * (Y * X) / float(fwd_px) if fwd_px else 0.0)
 
-    one = cpu_baseline((Y, X), Z, workload, 1, threads, seg=SEG)[0]
+    import tempfile
+    keep = os.path.join(tempfile.mkdtemp(prefix="tip_bench_"), "cpu_%s.npz" % workload)
+    one = cpu_baseline((Y, X), Z, workload, 1, threads, seg=SEG, keep=keep)[0]
     sec = frame_seconds(one, 1.0)
     seg_scale = (Y * X) / float(min(SEG, Y) * min(SEG, X))
     rec = {"value": 1.0 / sec, "unit": "frames/s", "cores": threads, "kind": "port", "host_cores": host_cores, "workload": workload,
            "sample": "one whole %dx%dx%d frame through the C/numpy oracle's projection (%.1f s on one core, unscaled); segmentation + "
                      "tables of the %s path on its %dx%d corner, scaled x%g by pixel count to %.1f s" % (Y, X, Z, one[0], workload, min(SEG, Y), min(SEG, X), seg_scale, one[1])}
+    rec["_outputs"] = keep          # (internal: consumed by label_parity_record, not printed)
     if workload == "unet":
         rec["sample"] += ("; network = the same float32 U-Net through torch-CPU on %d threads, 512^2 crop %.1f s scaled x%g "
                           "(%.2f TFLOP/s)" % (threads, one[2], (Y * X) / float(one[3]),
@@ -192,6 +203,69 @@ def cpu_baseline_record(Y, X, Z, workload):
                             "sample": "a %dx%dx%d crop (1/%g of a frame) in %d processes at once, scaled by pixel count: slowest %.1f s per frame"
                                       % (Ys, Xs, Z, scale, nproc, slowest)}
     return rec
+
+
+def _label_iou(test, ref):
+    """mean over the reference's labels of the IoU with the test label that covers most of it (1.0 for identical maps)"""
+    if np.array_equal(test, ref):
+        return 1.0
+    ious = []
+    for l in np.unique(ref):
+        if l == 0:
+            continue
+        m = ref == l
+        cand = np.bincount(test[m].clip(min=0))
+        cand[0] = 0
+        if cand.sum() == 0:
+            ious.append(0.0)
+            continue
+        k = cand.argmax()
+        ious.append((m & (test == k)).sum() / float((m | (test == k)).sum()))
+    return float(np.mean(ious)) if ious else 1.0
+
+
+def label_parity_record(cpu, Y, X, Z, device_index):
+    """BASELINE.json's metric has a second half, "label IoU vs ref": the GPU path on the SAME synthetic frame the cpu_baseline leg's oracle
+    processed (seed 1234), compared with what that leg computed -- projection and z-map bit for bit, the classical label map of the 1024^2
+    corner and the U-Net tail's label map / HC map on the oracle's probability crop (bit-exact flag + IoU).  Runs after the timed legs.
+    The network itself (U2) has no reference to compare with (no TensorFlow, no trained weights): stated, not measured."""
+    from tissue_image_processing_amd import synthetic, surface_projection as sp, basic_image_manipulations as bim
+    out = {"reference": "the cpu_baseline leg's outputs (C/numpy oracle, itself pinned by reference-generated goldens) on the same synthetic "
+                        "%dx%dx%d frame (seed 1234)" % (Y, X, Z)}
+    st = synthetic.make_stack(Z, Y, X, seed=1234)
+    proj, zmap = sp.time_point_surface_projection(st[None], "TCZYX", 0, airyscan=False, z_map=True)
+    recs = [(cpu.get("workload"), cpu.get("_outputs"))] + ([("classical", cpu["classical"].get("_outputs"))] if isinstance(cpu.get("classical"), dict) else [])
+    for wl, path in recs:
+        if not path or not os.path.exists(path):
+            continue
+        z = np.load(path)
+        if "projection_bit_exact" not in out:
+            out["projection_bit_exact"] = bool(np.array_equal(proj, z["proj"]))
+            out["projection_max_abs_diff"] = float(np.abs(proj - z["proj"]).max())
+            out["zmap_bit_exact"] = bool(np.array_equal(zmap, z["zmap"]))
+        ref = z["lab"]
+        if wl == "classical":
+            sy, sx = ref.shape
+            lab = bim.watershed_segmentation(np.ascontiguousarray(z["proj"][0][:sy, :sx]), 0.03, 3, 3)
+            out["classical_labels"] = {"bit_exact": bool(np.array_equal(lab, ref)), "iou": _label_iou(lab, ref), "labels": int(ref.max()),
+                                       "pixels": int(ref.size), "what": "watershed_segmentation(0.03, 3, 3) of the projection's %dx%d corner" % (sy, sx)}
+        elif wl == "unet":
+            import torch
+            from tissue_image_processing_amd.prediction_local import SegmentationPredictor
+            p0 = torch.from_numpy(z["p0"]).to(torch.device("cuda", device_index))
+            pred = SegmentationPredictor(None, (2,) + tuple(z["p0"].shape), device=device_index)
+            lab, hc = pred.segment_probability(p0)
+            out["unet_tail_labels"] = {"bit_exact": bool(np.array_equal(lab, ref)), "iou": _label_iou(lab, ref), "hc_bit_exact": bool(np.array_equal(hc, z["hc"])),
+                                       "labels": int(ref.max()), "pixels": int(ref.size),
+                                       "what": "threshold / 101 closings / erosion / boundary / watershed (pl.py:167-194) on the %dx%d probability map of the "
+                                               "cpu_baseline leg's float32 network" % tuple(z["p0"].shape)}
+            out["unet_network"] = "unpinned: no TensorFlow and no trained weights here or upstream; kernels vs the float64 evaluation of the same layers: tests"
+        try:
+            os.remove(path)
+            os.rmdir(os.path.dirname(path))
+        except OSError:
+            pass
+    return out
 
 
 # ---- --gpus N without a launcher: this process starts the N ranks ------------------------------------------------------------
@@ -871,6 +945,13 @@ def main():
         if second is not None:
             out[second["workload"]] = dict(leg_object(second), note="secondary leg, timed right after the headline leg in the same process")
         if cpu is not None:
+            try:
+                out["label_parity"] = label_parity_record(cpu, Y, X, Z, local_rank)
+            except Exception as e:      # the parity record must not cost the run its line
+                out["label_parity"] = {"error": repr(e)}
+            for c in (cpu, cpu.get("classical")):
+                if isinstance(c, dict):
+                    c.pop("_outputs", None)
             out["cpu_baseline"] = cpu
         if unet_modes is not None:
             out["unet_arithmetic_modes"] = unet_modes
